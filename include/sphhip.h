@@ -1,0 +1,199 @@
+/*
+ * sphhip.h -- C ABI of the MI355X-native SPH step (libsphhip.so).
+ *
+ * Drop-in boundary for the step interface of the alphazm/SPH reference.  Every entry point
+ * cites the reference interface it replaces (paths relative to the reference tree).  Plain C:
+ * POD structs, raw pointers and sizes, int error codes.  No HIP / torch types appear here on
+ * purpose: the reference's host header defines its own global `struct float2` (SPH/sph.h:22-25)
+ * which collides with HIP's, so host code that includes sph.h can include this file safely.
+ *
+ * Particle record (SPH/sph.h:27-33, duplicated SPH/sph.cuh:25-31): 28 bytes,
+ *   pos.x pos.y @0, vel.x vel.y @8, density @16, pressure @20, valid(bool) @24, 3 pad bytes.
+ * Host arrays handed to this library use exactly that layout and the reference's index order;
+ * the library's internal (cell-sorted, SoA) order is never visible through upload/download.
+ *
+ * Error convention: every function returns 0 on success, a negative SPHHIP_E* code otherwise
+ * (the reference's CUDA_CHECK prints and calls exit(1), SPH/sph.cuh:17-23; a library must not).
+ * sphhip_last_error() returns a human-readable message for the calling thread's last failure.
+ */
+#ifndef SPHHIP_H
+#define SPHHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPHHIP_PARTICLE_BYTES 28
+
+enum {
+    SPHHIP_OK = 0,
+    SPHHIP_EINVAL = -1,   /* bad argument (null pointer, n out of range, bad column range ...) */
+    SPHHIP_EHIP = -2,     /* a HIP runtime call failed; see sphhip_last_error() */
+    SPHHIP_ESTATE = -3,   /* call order violated (e.g. forces before any upload) */
+    SPHHIP_ECAPACITY = -4 /* more particles / cells than the context was created for */
+};
+
+/*
+ * Simulation constants.  The defaults (sphhip_default_params) reproduce the reference's
+ * compile-time #defines bit for bit (SPH/sph.h:11-20) together with the literals that are
+ * hard-coded in its step (SPH/sph.cpp:77 gravity 10.0f, :81-84 mouse radius 0.25f,
+ * :91-92 force cap 1000.0f, :113-128 walls 0.05f / 1.95f).  Making the walls parameters is what
+ * lets the 1M..64M-particle scenes keep ~50 neighbours per particle: the reference's fixed
+ * 1.9 x 1.9 box makes the neighbour count grow linearly with N.
+ */
+typedef struct SphParams {
+    float h;            /* H            0.15f   smoothing radius                     */
+    float dt;           /* DT           0.0005f                                      */
+    float mass;         /* MASS         0.05f                                        */
+    float viscosity;    /* VISCOSITY    0.3f                                         */
+    float stiffness;    /* STIFFNESS    1000.0f                                      */
+    float rest_density; /* REST_DENSITY 1000.0f                                      */
+    float damping;      /* DAMPING      0.9f    wall restitution                     */
+    float max_vel;      /* MAX_VEL      5.0f                                         */
+    float sigma;        /* SIGMA        0.05f   Lennard-Jones                        */
+    float epsilon;      /* EPSILON      1.0f    Lennard-Jones                        */
+    float gravity;      /* 10.0f   (sph.cpp:77)                                      */
+    float force_cap;    /* 1000.0f (sph.cpp:91-92), multiplied by the density        */
+    float mouse_radius; /* 0.25f   (sph.cpp:81-84)                                   */
+    float xmin, xmax;   /* walls, 0.05f / 1.95f (sph.cpp:113-120)                    */
+    float ymin, ymax;   /* walls, 0.05f / 1.95f (sph.cpp:121-128)                    */
+    float cell_size;    /* uniform-grid cell width; 0 => h * (1 + 1/256).  Must be   */
+                        /* > h so that every pair with r2 < h*h lies in the 3x3      */
+                        /* stencil despite fp32 rounding of the cell coordinate.     */
+} SphParams;
+
+/* Values derived from SphParams on the host with the reference's own expression order
+ * (powf on constants only: sph.cpp:11,18,25).  Exposed so tests can pin them. */
+typedef struct SphDerived {
+    float h2;          /* h*h                                     0x3cb851ec at defaults */
+    float poly6;       /* 315/(64*3.14159f*powf(h,9))             0x4c1b75da            */
+    float spiky;       /* -45/(3.14159f*powf(h,6))                0xc999818a            */
+    float visc_lap;    /* 45/(3.14159f*powf(h,6))                 0x4999818a            */
+    float visc_mass;   /* viscosity*mass                          0x3c75c290            */
+    float lj_cut;      /* 2.5f*sigma                              0x3e000000            */
+    float lj_24eps;    /* 24.0f*epsilon                                                 */
+    float neg_mass;    /* -mass                                                         */
+    float mouse_r2;    /* mouse_radius*mouse_radius                                     */
+    float cell;        /* effective cell width                                          */
+    float inv_cell;    /* 1.0f / cell                                                   */
+    int   nx, ny;      /* grid columns (x) and rows (y)                                 */
+} SphDerived;
+
+typedef struct SphCtx SphCtx; /* opaque; owns all device memory (no hidden globals, cf. sph.cu:10) */
+
+/* ---- parameters ------------------------------------------------------------------------- */
+
+/* Constants of SPH/sph.h:11-20 + the literals listed above. */
+int sphhip_default_params(SphParams* out);
+/* Host-side derivation (no GPU needed). */
+int sphhip_derive(const SphParams* p, SphDerived* out);
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device` able to hold n_max particles.
+ * Replaces the hidden global `d_particles` + cudaMalloc of initSimulation (SPH/sph.cu:10,166-169). */
+int sphhip_create(const SphParams* p, int n_max, int device, SphCtx** out);
+/* Replaces cleanupSimulation (SPH/sph.cu:275-280). */
+int sphhip_destroy(SphCtx* ctx);
+/* Run on a caller-owned HIP stream (hipStream_t as void*; NULL => the context's own stream). */
+int sphhip_set_stream(SphCtx* ctx, void* hip_stream);
+int sphhip_get_stream(SphCtx* ctx, void** hip_stream);
+int sphhip_synchronize(SphCtx* ctx);
+const char* sphhip_last_error(void);
+
+/* ---- state transfer --------------------------------------------------------------------- */
+
+/* Host AoS (28-byte records, reference index order) -> device.  Replaces the H2D copy of
+ * initSimulation / CUDA_performance_test (SPH/sph.cu:202,243).  Particle i gets global id
+ * id_base + i.  Invalidates the cell list. */
+int sphhip_upload(SphCtx* ctx, const void* aos28, int n, int id_base);
+/* Device -> host AoS, un-permuted to ascending id (record k = k-th smallest id; with
+ * id_base=0 that is the reference's index order).  Replaces the full D2H of stepSimulation
+ * (SPH/sph.cu:235). */
+int sphhip_download(SphCtx* ctx, void* aos28, int n);
+int sphhip_count(SphCtx* ctx, int* n);
+
+/* ---- phases of the step (SPH/sph.h:35-39; device flavour SPH/sph.cuh:33-38) ------------ */
+
+/* Neighbour search: cell hash, LDS-local radix sort, cell start/end.  No counterpart in the
+ * reference beyond the dead `int* grid, int* cellStart, int* cellEnd` parameters of its kernels
+ * (SPH/sph.cuh:33-34,38; always nullptr, SPH/sph.cu:222-223).  Reorders the device state into
+ * (cell key, id) order. */
+int sphhip_build_grid(SphCtx* ctx);
+/* serial_computeDensityPressure (SPH/sph.cpp:41-55) / computeDensityPressure (SPH/sph.cu:48-66). */
+int sphhip_density(SphCtx* ctx);
+/* serial_computeForces (SPH/sph.cpp:57-99) / computeForces (SPH/sph.cu:68-129): pair forces,
+ * gravity, mouse force, force clamp, velocity update.  Neighbour velocities are read from the
+ * state as it was when the call started (snapshot / Jacobi semantics, as mpi_computeStep does,
+ * SPH/MPI_sph.cpp:144-147,181); the serial loop's in-place update (sph.cpp:96-97) is inherently
+ * sequential. */
+int sphhip_forces(SphCtx* ctx, float mouse_x, float mouse_y, float strength);
+/* serial_integrate (SPH/sph.cpp:101-130) / integrate (SPH/sph.cu:131-164). */
+int sphhip_integrate(SphCtx* ctx);
+/* serial_stepSimulation (SPH/sph.cpp:166-171) x nsteps with the state resident on the device:
+ * grid, density, then forces + velocity update + integrate + wall clamp fused in one kernel.
+ * Replaces the 3-kernel loop of CUDA_performance_test (SPH/sph.cu:254-258). */
+int sphhip_step(SphCtx* ctx, float mouse_x, float mouse_y, float strength, int nsteps);
+
+/* ---- cell-list and neighbour diagnostics (parity: bit-exact integers) ------------------- */
+
+/* Any pointer may be NULL.  keys[n]: cell key per sorted slot; order[n]: particle id per sorted
+ * slot; cell_start/cell_end[nx*ny]: half-open slot range of each cell (empty: start==end).
+ * Requires a valid grid (sphhip_build_grid or a step). */
+int sphhip_get_cells(SphCtx* ctx, int* keys, int* order, int* cell_start, int* cell_end);
+/* counts[k] = #{j : r2 < h*h} including self (the reference predicate, sph.cpp:46-48), for the
+ * k-th smallest id.  Written by the most recent density pass. */
+int sphhip_get_neighbor_counts(SphCtx* ctx, int* counts, int n);
+
+/* ---- slab decomposition hooks (replace the index-block + Allgather scheme of
+ *      mpi_computeStep, SPH/MPI_sph.cpp:135-166,255-257) --------------------------------- */
+
+/* Restrict density / forces / integrate to particles whose cell column is in [col_lo, col_hi)
+ * (density is evaluated one column wider on each side so that ghost densities are recomputed
+ * locally instead of exchanged, cf. the dens/pres Allgathers MPI_sph.cpp:163-166).
+ * Default: all columns. */
+int sphhip_set_owned_columns(SphCtx* ctx, int col_lo, int col_hi);
+/* Packs, as 20-byte records {x,y,vx,vy,idv}, every particle whose column is < send_hi_left
+ * (for the left neighbour) or >= send_lo_right (for the right neighbour) into the device
+ * buffers d_left / d_right (capacity in records).  Returns the counts (after a stream sync).
+ * Positions are the current ones; the grid is not required. */
+int sphhip_pack_halo(SphCtx* ctx, int send_hi_left, int send_lo_right,
+                     void* d_left, int cap_left, int* n_left,
+                     void* d_right, int cap_right, int* n_right);
+/* Drops every particle whose column is outside [col_lo, col_hi) (ghosts of the last step and
+ * particles that migrated away), keeping order. */
+int sphhip_keep_columns(SphCtx* ctx, int col_lo, int col_hi);
+/* Appends n 20-byte records (device memory) to the state; density/pressure of the new
+ * particles are undefined until the next density pass. */
+int sphhip_append(SphCtx* ctx, const void* d_records, int n);
+/* Per-column particle histogram (nx ints, host) of the current positions: input of the
+ * count-balanced slab boundaries. */
+int sphhip_column_histogram(SphCtx* ctx, int* hist);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+
+enum {
+    SPHHIP_PH_HASH = 0,
+    SPHHIP_PH_SORT,
+    SPHHIP_PH_CELLS,
+    SPHHIP_PH_REORDER,
+    SPHHIP_PH_DENSITY,
+    SPHHIP_PH_FORCE,      /* force (+ fused integrate inside sphhip_step) */
+    SPHHIP_PH_INTEGRATE,  /* stand-alone integrate */
+    SPHHIP_PH_COUNT
+};
+/* When enabled, every phase is bracketed by HIP events on the context's stream. */
+int sphhip_set_profiling(SphCtx* ctx, int enable);
+/* Sums since the last reset: milliseconds and launches per phase (arrays of SPHHIP_PH_COUNT). */
+int sphhip_get_phase_times(SphCtx* ctx, float* ms, int* launches);
+int sphhip_reset_phase_times(SphCtx* ctx);
+/* Total in-range pairs (j != i, r2 < h*h) counted by the most recent density pass. */
+int sphhip_get_pair_count(SphCtx* ctx, long long* pairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHHIP_H */

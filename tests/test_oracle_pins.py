@@ -1,0 +1,184 @@
+"""Pins the CPU oracle (oracle/sph_oracle.c): against the committed golden vectors generated from the
+reference's own serial step (oracle/make_golden.py), and -- where oracle/_ref is built, i.e. in the
+container that has /root/reference -- directly against the compiled reference on fresh inputs.
+Bar: bit-exact (the oracle restates the same IEEE binary32 expression order)."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from sph_amd.params import PARTICLE_DTYPE
+
+O = orc.Oracle()
+P = O.default_params()
+
+
+def G(name):
+    return np.load(os.path.join(orc.GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def test_particle_layout():
+    assert PARTICLE_DTYPE.itemsize == 28  # SPH/sph.h:27-33
+    assert [PARTICLE_DTYPE.fields[k][1] for k in ("pos", "vel", "density", "pressure", "valid")] == [0, 8, 16, 20, 24]
+
+
+def test_init_lattice_golden():
+    g = G("f1_init")
+    for k in g.files:
+        n = int(k[1:])
+        assert orc.same_bits(O.init_lattice(n), g[k]), k
+    a = g["n1024"]
+    # spacing 0x3d7b0b91, p0 = (0.05f, 1.95f)
+    assert a["pos"][0].tobytes() == np.array([0.05, 1.95], np.float32).tobytes()
+    assert np.float32(a["pos"][1, 0] - a["pos"][0, 0]) > 0
+
+
+def test_serial_trajectory_golden():
+    g = G("f2_serial_traj_n1024")
+    a = g["s0"].copy()
+    done = 0
+    for s in (1, 10, 50, 100, 200):
+        O.step_allpairs(P, a, s - done, flags=orc.GAUSS_SEIDEL)
+        done = s
+        assert orc.same_bits(a, g["s%d" % s]), "serial trajectory differs at step %d" % s
+    # SURVEY 8(c) provisional pins, N=1024 after 10 serial steps
+    s10 = g["s10"]
+    assert s10["pos"][0].tobytes() == np.array([0.0500128306, 1.94984972], np.float32).tobytes()
+    assert s10["vel"][0].tobytes() == np.array([0.00466268416, -0.0546627231], np.float32).tobytes()
+    assert abs(float(s10["density"].astype(np.float64).mean()) - 104.910013) < 1e-4
+
+
+def test_snapshot_trajectory_and_survey_pin():
+    g = G("f3_snapshot_traj_n1024")
+    a = g["s0"].copy()
+    O.step_allpairs(P, a, 50, flags=orc.SNAPSHOT | orc.EPS_F32)
+    assert orc.same_bits(a, g["s50"])
+    pin = g["survey_pin_s50_p0v0"]  # recorded by the survey from the 1-rank MPI build
+    got = np.array([a["pos"][0, 0], a["pos"][0, 1], a["vel"][0, 0], a["vel"][0, 1]], np.float32)
+    assert got.tobytes() == pin.tobytes()
+    # snapshot != Gauss-Seidel, but close (max |dv| 2.2e-4 after 100 steps)
+    s = G("f2_serial_traj_n1024")["s50"]
+    assert not orc.same_bits(a, s)
+    assert np.abs(a["vel"] - s["vel"]).max() < 1e-3
+
+
+def test_phases_golden():
+    for name in ("f4_phases_n1024", "f5_dense_block"):
+        g = G(name)
+        d = O.density_allpairs(P, g["state"].copy())
+        assert orc.same_bits(d, g["after_density"]), name
+        f = O.forces_allpairs(P, g["after_density"].copy())
+        assert orc.same_bits(f, g["after_forces"]), name
+        i = O.integrate(P, g["after_forces"].copy())
+        assert orc.same_bits(i, g["after_integrate"]), name
+    g = G("f5_dense_block")
+    assert g["after_density"]["pressure"].max() > 0  # pressure branch exercised
+    assert orc.same_bits(O.step_allpairs(P, g["state"].copy(), 3), g["after_3steps"])
+
+
+def test_mouse_golden():
+    g = G("f6_mouse")
+    for k in ("push", "pull"):
+        mx, my, s = [float(x) for x in g[k + "_args"]]
+        out = O.forces_allpairs(P, g["state"].copy(), (mx, my), s)
+        assert orc.same_bits(out, g[k]), k
+    assert not orc.same_bits(g["push"], g["pull"])
+
+
+def test_walls_golden():
+    g = G("f7_walls")
+    out = O.integrate(P, g["state"].copy())
+    assert orc.same_bits(out, g["after_integrate"])
+    assert orc.same_bits(out[10:11], g["state"][10:11])  # valid=false is skipped (sph.cpp:103)
+
+
+def test_invalid_golden():
+    g = G("f9_invalid")
+    assert orc.same_bits(O.step_allpairs(P, g["state"].copy(), 1), g["after_1step"])
+    assert orc.same_bits(O.step_allpairs(P, g["state"].copy(), 5), g["after_5steps"])
+
+
+def test_kernel_tables_golden():
+    g = G("f10_kernel_tables")
+    h, sig, eps = np.float32(0.15), np.float32(0.05), np.float32(1.0)
+    for i, r in enumerate(g["r"]):
+        r = np.float32(r)
+        assert np.float32(O.L.orc_poly6(np.float32(r * r), h)).tobytes() == g["poly6"][i].tobytes()
+        assert np.float32(O.L.orc_visc_lap(r, h)).tobytes() == g["visc"][i].tobytes()
+        c = np.float32(O.L.orc_spiky_coeff(r, h, 0))
+        v = np.array([c * np.float32(np.float32(0.6) * r), c * np.float32(np.float32(0.8) * r)], np.float32)
+        assert v.tobytes() == g["spiky"][i].tobytes(), r
+        c = np.float32(O.L.orc_lj_coeff(r, sig, eps))
+        v = np.array([c * np.float32(np.float32(0.6) * r), c * np.float32(np.float32(0.8) * r)], np.float32)
+        assert v.tobytes() == g["lj"][i].tobytes(), r
+
+
+def test_short_runs_golden():
+    g = G("f11_short_runs")
+    for k in g.files:
+        n, s = int(k.split("_")[0][1:]), int(k.split("_")[1][1:])
+        a = O.step_allpairs(P, O.init_lattice(n), s)
+        assert orc.same_bits(a, g[k]), k
+
+
+def test_cell_list_matches_all_pairs_predicate():
+    """Neighbour counts from the 3x3 stencil == reference predicate over all pairs (bit-exact ints),
+    and the cell list itself is a sorted partition."""
+    g8 = G("f8_neighbor_counts")
+    for state, key in ((G("f2_serial_traj_n1024")["s1"], "n1024_s1"), (G("f2_serial_traj_n1024")["s100"], "n1024_s100"),
+                       (G("f5_dense_block")["state"], "dense")):
+        a = state.copy()
+        _, cnt = O.density_cells(P, a)
+        assert np.array_equal(cnt, g8[key])
+        assert np.array_equal(cnt, O.neighbor_counts_allpairs(P, state))
+        keys, order, skeys, cs = O.build_cells(P, state)
+        assert np.all(np.diff(skeys) >= 0)
+        assert np.array_equal(keys[order], skeys)
+        same = np.diff(skeys) == 0
+        assert np.all(np.diff(order)[same] > 0)  # ties broken by ascending id
+        assert cs[0] == 0 and cs[-1] == len(state) and np.all(np.diff(cs) >= 0)
+        # density sums differ from all-pairs only by summation order
+        d = O.density_allpairs(P, state.copy())
+        assert np.allclose(a["density"], d["density"], rtol=2e-6, atol=0)
+
+
+def test_cell_step_close_to_snapshot_allpairs():
+    a = O.init_lattice(1024)
+    b = a.copy()
+    O.step_cells(P, a, 10)
+    O.step_allpairs(P, b, 10, flags=orc.SNAPSHOT)
+    assert np.abs(a["pos"] - b["pos"]).max() < 1e-6
+    assert np.abs(a["vel"] - b["vel"]).max() < 1e-5
+
+
+def test_omp_port_runs_and_is_close():
+    a = O.init_lattice(1024)
+    b = a.copy()
+    O.omp_step_allpairs(P, a, 5)
+    O.step_allpairs(P, b, 5, flags=orc.SNAPSHOT)
+    assert np.abs(a["pos"] - b["pos"]).max() < 1e-5
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+def test_oracle_vs_compiled_reference_random_states():
+    R = orc.Reference()
+    rng = np.random.default_rng(7)
+    for n, lo, hi in ((300, 0.3, 0.9), (777, 0.05, 1.95), (500, 0.9, 1.1)):
+        a = np.zeros(n, PARTICLE_DTYPE)
+        a["pos"] = rng.uniform(lo, hi, (n, 2)).astype(np.float32)
+        a["vel"] = rng.normal(0, 1.5, (n, 2)).astype(np.float32)
+        a["density"] = 1000.0
+        a["valid"] = rng.random(n) > 0.05
+        a["pos"][1] = a["pos"][0]  # coincident pair: r_len < 1e-6 guards
+        for mouse, strength in (((0.0, 0.0), 0.0), ((0.6, 0.6), 50000.0)):
+            x, y = a.copy(), a.copy()
+            for _ in range(3):
+                R.density(x), O.density_allpairs(P, y)
+                assert orc.same_bits(x, y)
+                R.forces(x, mouse, strength), O.forces_allpairs(P, y, mouse, strength)
+                assert orc.same_bits(x, y)
+                R.integrate(x), O.integrate(P, y)
+                assert orc.same_bits(x, y)
+    for n in (1, 2, 3, 7, 64, 1023, 1025, 5000):
+        assert orc.same_bits(R.init(n), O.init_lattice(n))
