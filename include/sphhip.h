@@ -103,6 +103,11 @@ int sphhip_set_stream(SphCtx* ctx, void* hip_stream);
 int sphhip_get_stream(SphCtx* ctx, void** hip_stream);
 int sphhip_synchronize(SphCtx* ctx);
 const char* sphhip_last_error(void);
+/* Pair-kernel tuning: cells of one grid column per workgroup (1..64) and neighbour candidates
+ * staged in LDS per workgroup (64..6144); 0 keeps the current value.  Results do not depend on
+ * either (the per-particle summation order is fixed).  No counterpart in the reference
+ * (its launch geometry is hard-coded, SPH/sph.cu:219-220). */
+int sphhip_set_tuning(SphCtx* ctx, int tile_cells, int pair_cap);
 
 /* ---- state transfer --------------------------------------------------------------------- */
 
@@ -114,6 +119,9 @@ int sphhip_upload(SphCtx* ctx, const void* aos28, int n, int id_base);
  * id_base=0 that is the reference's index order).  Replaces the full D2H of stepSimulation
  * (SPH/sph.cu:235). */
 int sphhip_download(SphCtx* ctx, void* aos28, int n);
+/* Same, and also returns the id of every record (ids[k], ascending): what a slab rank needs to
+ * place its particles in the global array. */
+int sphhip_download_ids(SphCtx* ctx, void* aos28, int* ids, int n);
 int sphhip_count(SphCtx* ctx, int* n);
 
 /* ---- phases of the step (SPH/sph.h:35-39; device flavour SPH/sph.cuh:33-38) ------------ */
@@ -156,15 +164,16 @@ int sphhip_get_neighbor_counts(SphCtx* ctx, int* counts, int n);
  * locally instead of exchanged, cf. the dens/pres Allgathers MPI_sph.cpp:163-166).
  * Default: all columns. */
 int sphhip_set_owned_columns(SphCtx* ctx, int col_lo, int col_hi);
-/* Packs, as 20-byte records {x,y,vx,vy,idv}, every particle whose column is < send_hi_left
- * (for the left neighbour) or >= send_lo_right (for the right neighbour) into the device
- * buffers d_left / d_right (capacity in records).  Returns the counts (after a stream sync).
- * Positions are the current ones; the grid is not required. */
+/* Classifies every particle by the grid column of its CURRENT position.  Copies it, as a 20-byte
+ * record {x,y,vx,vy,idv}, into d_left if column < send_hi_left and into d_right if column >=
+ * send_lo_right (device buffers, capacity in records; migrants and ghosts for the neighbour
+ * slabs), and keeps it only if its column is inside the owned range set by
+ * sphhip_set_owned_columns (this drops last step's ghosts and the particles that migrated
+ * away).  Returns the two counts after a stream sync.  The grid is not required. */
 int sphhip_pack_halo(SphCtx* ctx, int send_hi_left, int send_lo_right,
                      void* d_left, int cap_left, int* n_left,
                      void* d_right, int cap_right, int* n_right);
-/* Drops every particle whose column is outside [col_lo, col_hi) (ghosts of the last step and
- * particles that migrated away), keeping order. */
+/* Drops every particle whose column is outside [col_lo, col_hi); sends nothing. */
 int sphhip_keep_columns(SphCtx* ctx, int col_lo, int col_hi);
 /* Appends n 20-byte records (device memory) to the state; density/pressure of the new
  * particles are undefined until the next density pass. */

@@ -1,0 +1,647 @@
+// ctx.hip -- context, memory, state transfer, slab hooks and the extern "C" surface of libsphhip.so.
+// Entry points and the reference interfaces they replace are documented in include/sphhip.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include "sphhip_internal.h"
+
+// ---- error plumbing -------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void sph_set_error(const std::string& msg) { g_last_error = msg; }
+
+int sph_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_last_error = buf;
+    return SPHHIP_EHIP;
+}
+
+static int fail(int code, const char* msg) {
+    g_last_error = msg;
+    return code;
+}
+
+// ---- phase timing ---------------------------------------------------------------------------
+void sph_phase_begin(SphCtx* c, int ph) {
+    if (!c->profiling) return;
+    PhaseTimer& t = c->timer;
+    if (t.used[ph] == t.start[ph].size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        t.start[ph].push_back(a);
+        t.stop[ph].push_back(b);
+    }
+    hipEventRecord(t.start[ph][t.used[ph]], c->stream);
+}
+
+void sph_phase_end(SphCtx* c, int ph) {
+    if (!c->profiling) return;
+    PhaseTimer& t = c->timer;
+    if (t.used[ph] >= t.stop[ph].size()) return;
+    hipEventRecord(t.stop[ph][t.used[ph]], c->stream);
+    t.used[ph]++;
+}
+
+static void timer_flush(SphCtx* c) {
+    PhaseTimer& t = c->timer;
+    for (int ph = 0; ph < SPHHIP_PH_COUNT; ph++) {
+        for (size_t i = 0; i < t.used[ph]; i++) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, t.start[ph][i], t.stop[ph][i]) == hipSuccess) {
+                t.ms[ph] += ms;
+                t.launches[ph]++;
+            }
+        }
+        t.used[ph] = 0;
+    }
+}
+
+// ---- parameters -----------------------------------------------------------------------------
+extern "C" int sphhip_default_params(SphParams* p) {
+    if (!p) return fail(SPHHIP_EINVAL, "sphhip_default_params: null");
+    p->h = 0.15f;
+    p->dt = 0.0005f;
+    p->mass = 0.05f;
+    p->viscosity = 0.3f;
+    p->stiffness = 1000.0f;
+    p->rest_density = 1000.0f;
+    p->damping = 0.9f;
+    p->max_vel = 5.0f;
+    p->sigma = 0.05f;
+    p->epsilon = 1.0f;
+    p->gravity = 10.0f;
+    p->force_cap = 1000.0f;
+    p->mouse_radius = 0.25f;
+    p->xmin = 0.05f;
+    p->xmax = 1.95f;
+    p->ymin = 0.05f;
+    p->ymax = 1.95f;
+    p->cell_size = 0.0f;
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_derive(const SphParams* p, SphDerived* d) {
+    if (!p || !d) return fail(SPHHIP_EINVAL, "sphhip_derive: null");
+    if (!(p->h > 0.0f) || !(p->xmax > p->xmin) || !(p->ymax > p->ymin))
+        return fail(SPHHIP_EINVAL, "sphhip_derive: need h > 0 and max > min walls");
+    // expression order of SPH/sph.cpp:11,18,25,30,37,70,72,81
+    d->h2 = p->h * p->h;
+    d->poly6 = 315.0f / (64.0f * 3.14159f * powf(p->h, 9));
+    d->spiky = -45.0f / (3.14159f * powf(p->h, 6));
+    d->visc_lap = 45.0f / (3.14159f * powf(p->h, 6));
+    d->visc_mass = p->viscosity * p->mass;
+    d->lj_cut = 2.5f * p->sigma;
+    d->lj_24eps = 24.0f * p->epsilon;
+    d->neg_mass = -p->mass;
+    d->mouse_r2 = p->mouse_radius * p->mouse_radius;
+    d->cell = (p->cell_size > 0.0f) ? p->cell_size : p->h * 1.00390625f;
+    if (!(d->cell > p->h)) return fail(SPHHIP_EINVAL, "sphhip_derive: cell_size must exceed h");
+    d->inv_cell = 1.0f / d->cell;
+    double fx = std::floor((double)((p->xmax - p->xmin) * d->inv_cell)) + 1.0;
+    double fy = std::floor((double)((p->ymax - p->ymin) * d->inv_cell)) + 1.0;
+    if (fx * fy > 1.0e9) return fail(SPHHIP_EINVAL, "sphhip_derive: grid too large (> 1e9 cells)");
+    d->nx = (int)floorf((p->xmax - p->xmin) * d->inv_cell) + 1;
+    d->ny = (int)floorf((p->ymax - p->ymin) * d->inv_cell) + 1;
+    if (d->nx < 1) d->nx = 1;
+    if (d->ny < 1) d->ny = 1;
+    return SPHHIP_OK;
+}
+
+static void fill_dev_consts(const SphParams& p, const SphDerived& d, DevConsts& c) {
+    c.h = p.h;
+    c.h2 = d.h2;
+    c.poly6 = d.poly6;
+    c.spiky = d.spiky;
+    c.visc_lap = d.visc_lap;
+    c.visc_mass = d.visc_mass;
+    c.neg_mass = d.neg_mass;
+    c.lj_cut = d.lj_cut;
+    c.lj24 = d.lj_24eps;
+    c.sigma = p.sigma;
+    c.mass = p.mass;
+    c.stiffness = p.stiffness;
+    c.rest_density = p.rest_density;
+    c.gravity = p.gravity;
+    c.force_cap = p.force_cap;
+    c.mouse_radius = p.mouse_radius;
+    c.mouse_r2 = d.mouse_r2;
+    c.dt = p.dt;
+    c.max_vel = p.max_vel;
+    c.damping = p.damping;
+    c.xmin = p.xmin;
+    c.xmax = p.xmax;
+    c.ymin = p.ymin;
+    c.ymax = p.ymax;
+    c.inv_cell = d.inv_cell;
+    c.nx = d.nx;
+    c.ny = d.ny;
+}
+
+// ---- context --------------------------------------------------------------------------------
+template <typename T>
+static hipError_t dmalloc(T** p, size_t count) {
+    return hipMalloc((void**)p, sizeof(T) * std::max<size_t>(count, 1));
+}
+
+static void free_all(SphCtx* c) {
+    void* ptrs[] = {c->pos, c->vel, c->pos2, c->vel2, c->rho, c->prs, c->rho2, c->prs2, c->idv, c->idv2,
+                    c->ncount, c->keys, c->keys2, c->perm, c->perm2, c->ids_sorted, c->cell_start, c->block_hist,
+                    c->digit_total, c->scan_tmp, c->counters, c->staging};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int ph = 0; ph < SPHHIP_PH_COUNT; ph++) {
+        for (hipEvent_t e : c->timer.start[ph]) (void)hipEventDestroy(e);
+        for (hipEvent_t e : c->timer.stop[ph]) (void)hipEventDestroy(e);
+    }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+}
+
+extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx** out) {
+    if (!p || !out) return fail(SPHHIP_EINVAL, "sphhip_create: null argument");
+    if (n_max < 1 || n_max > (1 << 30)) return fail(SPHHIP_EINVAL, "sphhip_create: n_max out of range");
+    SphDerived d;
+    int rc = sphhip_derive(p, &d);
+    if (rc) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(SPHHIP_EINVAL, "sphhip_create: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    SphCtx* c = new SphCtx();
+    c->params = *p;
+    c->drv = d;
+    fill_dev_consts(*p, d, c->dc);
+    c->device = device;
+    c->n_max = n_max;
+    c->ncell = d.nx * d.ny;
+    c->col_lo = 0;
+    c->col_hi = d.nx;
+    if (const char* e = getenv("SPHHIP_TILE_CELLS")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= PAIR_MAX_TILE_CELLS) c->tile_cells = v;
+    }
+    if (const char* e = getenv("SPHHIP_PAIR_CAP")) {
+        int v = atoi(e);
+        if (v >= 64 && v <= 6144) c->pair_cap = v;
+    }
+    const size_t n = (size_t)n_max;
+    const int nblocks = (n_max + SORT_TILE - 1) / SORT_TILE;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    ok(dmalloc(&c->pos, n)); ok(dmalloc(&c->vel, n)); ok(dmalloc(&c->pos2, n)); ok(dmalloc(&c->vel2, n));
+    ok(dmalloc(&c->rho, n)); ok(dmalloc(&c->prs, n)); ok(dmalloc(&c->rho2, n)); ok(dmalloc(&c->prs2, n));
+    ok(dmalloc(&c->idv, n)); ok(dmalloc(&c->idv2, n)); ok(dmalloc(&c->ncount, n));
+    ok(dmalloc(&c->keys, n)); ok(dmalloc(&c->keys2, n)); ok(dmalloc(&c->perm, n)); ok(dmalloc(&c->perm2, n));
+    ok(dmalloc(&c->ids_sorted, n));
+    ok(dmalloc(&c->cell_start, (size_t)c->ncell + 1));
+    ok(dmalloc(&c->block_hist, (size_t)SORT_RADIX * nblocks));
+    ok(dmalloc(&c->digit_total, 2 * SORT_RADIX));
+    ok(dmalloc(&c->scan_tmp, (size_t)(c->ncell + 1 + 2047) / 2048 + 1));
+    ok(dmalloc(&c->counters, 64));
+    ok(hipMalloc(&c->staging, std::max<size_t>(n * SPHHIP_PARTICLE_BYTES, 64)));
+    if (e != hipSuccess) {
+        free_all(c);
+        delete c;
+        return sph_hip_fail(e, "sphhip_create allocation", __FILE__, __LINE__);
+    }
+    *out = c;
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_destroy(SphCtx* c) {
+    if (!c) return SPHHIP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_all(c);
+    delete c;
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_set_stream(SphCtx* c, void* s) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_get_stream(SphCtx* c, void** s) {
+    if (!c || !s) return fail(SPHHIP_EINVAL, "null argument");
+    *s = (void*)c->stream;
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_synchronize(SphCtx* c) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPHHIP_OK;
+}
+
+extern "C" const char* sphhip_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int sphhip_set_tuning(SphCtx* c, int tile_cells, int pair_cap) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    if (tile_cells > 0) {
+        if (tile_cells > PAIR_MAX_TILE_CELLS) return fail(SPHHIP_EINVAL, "tile_cells too large");
+        c->tile_cells = tile_cells;
+    }
+    if (pair_cap > 0) {
+        if (pair_cap < 64 || pair_cap > 6144) return fail(SPHHIP_EINVAL, "pair_cap out of range [64, 6144]");
+        c->pair_cap = pair_cap;
+    }
+    return SPHHIP_OK;
+}
+
+// ---- AoS <-> SoA ----------------------------------------------------------------------------
+// 28-byte records are read/written as 7 dwords (SPH/sph.h:27-33: pos, vel, density, pressure,
+// valid byte + 3 pad).  Off the timed path.
+__global__ __launch_bounds__(256) void k_unpack_aos(const uint32_t* __restrict__ aos, int n, uint32_t id_base,
+                                                     float2* __restrict__ pos, float2* __restrict__ vel,
+                                                     float* __restrict__ rho, float* __restrict__ prs,
+                                                     uint32_t* __restrict__ idv) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* r = aos + (size_t)i * 7;
+    pos[i] = make_float2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    vel[i] = make_float2(__uint_as_float(r[2]), __uint_as_float(r[3]));
+    rho[i] = __uint_as_float(r[4]);
+    prs[i] = __uint_as_float(r[5]);
+    bool valid = (r[6] & 0xffu) != 0;
+    idv[i] = (id_base + (uint32_t)i) | (valid ? 0u : SPH_INVALID_BIT);
+}
+
+__global__ __launch_bounds__(256) void k_pack_aos(uint32_t* __restrict__ aos, int n, const float2* __restrict__ pos,
+                                                   const float2* __restrict__ vel, const float* __restrict__ rho,
+                                                   const float* __restrict__ prs, const uint32_t* __restrict__ idv,
+                                                   uint32_t* __restrict__ ids_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* r = aos + (size_t)i * 7;
+    float2 p = pos[i], v = vel[i];
+    r[0] = __float_as_uint(p.x);
+    r[1] = __float_as_uint(p.y);
+    r[2] = __float_as_uint(v.x);
+    r[3] = __float_as_uint(v.y);
+    r[4] = __float_as_uint(rho[i]);
+    r[5] = __float_as_uint(prs[i]);
+    uint32_t w = idv[i];
+    r[6] = (w & SPH_INVALID_BIT) ? 0u : 1u;
+    ids_out[i] = w & SPH_ID_MASK;
+}
+
+extern "C" int sphhip_upload(SphCtx* c, const void* aos28, int n, int id_base) {
+    if (!c || (!aos28 && n > 0)) return fail(SPHHIP_EINVAL, "sphhip_upload: null argument");
+    if (n < 0 || id_base < 0 || (long long)id_base + n > 0x7fffffffLL)
+        return fail(SPHHIP_EINVAL, "sphhip_upload: bad n / id_base");
+    if (n > c->n_max) return fail(SPHHIP_ECAPACITY, "sphhip_upload: n exceeds the context capacity");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(c->staging, aos28, (size_t)n * SPHHIP_PARTICLE_BYTES, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_unpack_aos, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)c->staging,
+                           n, (uint32_t)id_base, c->pos, c->vel, c->rho, c->prs, c->idv);
+        LAUNCH_CHECK();
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the host buffer is only borrowed for the call
+    c->n = n;
+    c->have_state = true;
+    c->grid_valid = false;
+    c->counts_valid = false;
+    return SPHHIP_OK;
+}
+
+static int download_impl(SphCtx* c, void* aos28, int* ids, int n) {
+    if (!c || (!aos28 && n > 0)) return fail(SPHHIP_EINVAL, "sphhip_download: null argument");
+    if (!c->have_state) return fail(SPHHIP_ESTATE, "sphhip_download: nothing uploaded");
+    if (n != c->n) return fail(SPHHIP_EINVAL, "sphhip_download: n differs from the particle count");
+    if (n == 0) return SPHHIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // ids_sorted doubles as the id staging buffer (it is rebuilt by every grid build)
+    hipLaunchKernelGGL(k_pack_aos, dim3((n + 255) / 256), dim3(256), 0, c->stream, (uint32_t*)c->staging, n, c->pos,
+                       c->vel, c->rho, c->prs, c->idv, c->ids_sorted);
+    LAUNCH_CHECK();
+    std::vector<unsigned char> rec((size_t)n * SPHHIP_PARTICLE_BYTES);
+    std::vector<uint32_t> id((size_t)n);
+    HIP_TRY(hipMemcpyAsync(rec.data(), c->staging, rec.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(id.data(), c->ids_sorted, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // un-permute to ascending id (the reference never permutes particles; index i is stable)
+    std::vector<int> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return id[a] < id[b]; });
+    unsigned char* out = (unsigned char*)aos28;
+    for (int k = 0; k < n; k++) {
+        memcpy(out + (size_t)k * SPHHIP_PARTICLE_BYTES, rec.data() + (size_t)order[k] * SPHHIP_PARTICLE_BYTES,
+               SPHHIP_PARTICLE_BYTES);
+        if (ids) ids[k] = (int)id[order[k]];
+    }
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_download(SphCtx* c, void* aos28, int n) { return download_impl(c, aos28, nullptr, n); }
+extern "C" int sphhip_download_ids(SphCtx* c, void* aos28, int* ids, int n) { return download_impl(c, aos28, ids, n); }
+
+extern "C" int sphhip_count(SphCtx* c, int* n) {
+    if (!c || !n) return fail(SPHHIP_EINVAL, "null argument");
+    *n = c->n;
+    return SPHHIP_OK;
+}
+
+// ---- phases ---------------------------------------------------------------------------------
+#define NEED_STATE(c)                                                            \
+    do {                                                                         \
+        if (!(c)) return fail(SPHHIP_EINVAL, "null context");                    \
+        if (!(c)->have_state) return fail(SPHHIP_ESTATE, "no particles uploaded"); \
+        HIP_TRY(hipSetDevice((c)->device));                                      \
+    } while (0)
+
+extern "C" int sphhip_build_grid(SphCtx* c) {
+    NEED_STATE(c);
+    return sph_grid_build(c, true);
+}
+
+extern "C" int sphhip_density(SphCtx* c) {
+    NEED_STATE(c);
+    if (!c->grid_valid) {
+        int rc = sph_grid_build(c, true);
+        if (rc) return rc;
+    }
+    return sph_density_launch(c);
+}
+
+extern "C" int sphhip_forces(SphCtx* c, float mx, float my, float strength) {
+    NEED_STATE(c);
+    if (!c->grid_valid) {
+        int rc = sph_grid_build(c, true);
+        if (rc) return rc;
+    }
+    return sph_force_launch(c, mx, my, strength, false);
+}
+
+extern "C" int sphhip_integrate(SphCtx* c) {
+    NEED_STATE(c);
+    return sph_integrate_launch(c);
+}
+
+extern "C" int sphhip_step(SphCtx* c, float mx, float my, float strength, int nsteps) {
+    NEED_STATE(c);
+    if (nsteps < 0) return fail(SPHHIP_EINVAL, "sphhip_step: nsteps < 0");
+    for (int s = 0; s < nsteps; s++) {
+        int rc = sph_grid_build(c, false);
+        if (rc) return rc;
+        rc = sph_density_launch(c);
+        if (rc) return rc;
+        rc = sph_force_launch(c, mx, my, strength, true);
+        if (rc) return rc;
+    }
+    return SPHHIP_OK;
+}
+
+// ---- diagnostics ----------------------------------------------------------------------------
+extern "C" int sphhip_get_cells(SphCtx* c, int* keys, int* order, int* cell_start, int* cell_end) {
+    NEED_STATE(c);
+    if (!c->grid_valid) return fail(SPHHIP_ESTATE, "sphhip_get_cells: no valid grid (positions changed since the last build)");
+    const int n = c->n;
+    if (keys && n) HIP_TRY(hipMemcpyAsync(keys, c->keys, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint32_t> idv;
+    if (order && n) {
+        idv.resize(n);
+        HIP_TRY(hipMemcpyAsync(idv.data(), c->idv, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    }
+    std::vector<int> cs;
+    if (cell_start || cell_end) {
+        cs.resize((size_t)c->ncell + 1);
+        HIP_TRY(hipMemcpyAsync(cs.data(), c->cell_start, sizeof(int) * cs.size(), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (order)
+        for (int i = 0; i < n; i++) order[i] = (int)(idv[i] & SPH_ID_MASK);
+    if (cell_start) memcpy(cell_start, cs.data(), sizeof(int) * (size_t)c->ncell);
+    if (cell_end) memcpy(cell_end, cs.data() + 1, sizeof(int) * (size_t)c->ncell);
+    return SPHHIP_OK;
+}
+
+static int fetch_counts_sorted_by_id(SphCtx* c, std::vector<int>& cnt, std::vector<uint32_t>& id) {
+    const int n = c->n;
+    cnt.resize(n);
+    id.resize(n);
+    if (n == 0) return SPHHIP_OK;
+    HIP_TRY(hipMemcpyAsync(cnt.data(), c->ncount, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(id.data(), c->idv, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_get_neighbor_counts(SphCtx* c, int* counts, int n) {
+    NEED_STATE(c);
+    if (!counts && n > 0) return fail(SPHHIP_EINVAL, "null argument");
+    if (n != c->n) return fail(SPHHIP_EINVAL, "sphhip_get_neighbor_counts: n differs from the particle count");
+    if (!c->counts_valid || !c->grid_valid)
+        return fail(SPHHIP_ESTATE, "sphhip_get_neighbor_counts: call after a density pass, before positions change");
+    std::vector<int> cnt;
+    std::vector<uint32_t> id;
+    int rc = fetch_counts_sorted_by_id(c, cnt, id);
+    if (rc) return rc;
+    std::vector<int> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return (id[a] & SPH_ID_MASK) < (id[b] & SPH_ID_MASK); });
+    for (int k = 0; k < n; k++) counts[k] = cnt[order[k]];
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_get_pair_count(SphCtx* c, long long* pairs) {
+    NEED_STATE(c);
+    if (!pairs) return fail(SPHHIP_EINVAL, "null argument");
+    if (!c->counts_valid) return fail(SPHHIP_ESTATE, "sphhip_get_pair_count: no density pass yet");
+    std::vector<int> cnt(c->n);
+    if (c->n) HIP_TRY(hipMemcpyAsync(cnt.data(), c->ncount, sizeof(int) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    long long t = 0;
+    for (int v : cnt) t += (v > 0 ? v - 1 : 0);  // self excluded
+    *pairs = t;
+    return SPHHIP_OK;
+}
+
+// ---- slab hooks -----------------------------------------------------------------------------
+extern "C" int sphhip_set_owned_columns(SphCtx* c, int lo, int hi) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    if (lo < 0 || hi > c->dc.nx || lo >= hi) return fail(SPHHIP_EINVAL, "sphhip_set_owned_columns: bad range");
+    c->col_lo = lo;
+    c->col_hi = hi;
+    return SPHHIP_OK;
+}
+
+struct HaloRec {
+    float x, y, vx, vy;
+    uint32_t idv;
+};
+static_assert(sizeof(HaloRec) == 20, "halo record");
+
+// Classifies every particle by the column of its current position: copies it to the left buffer
+// if col < send_hi_left, to the right buffer if col >= send_lo_right, and keeps it (compacted into
+// the *_o arrays) if keep_lo <= col < keep_hi.  Slot order of the outputs is arbitrary (atomics):
+// the next grid build sorts by (key, id), so results do not depend on it.
+__global__ __launch_bounds__(256) void k_split(DevConsts c, int n, const float2* __restrict__ pos,
+                                                const float2* __restrict__ vel, const float* __restrict__ rho,
+                                                const float* __restrict__ prs, const uint32_t* __restrict__ idv,
+                                                int send_hi_left, int send_lo_right, int keep_lo, int keep_hi,
+                                                HaloRec* __restrict__ left, int cap_left,
+                                                HaloRec* __restrict__ right, int cap_right,
+                                                float2* __restrict__ pos_o, float2* __restrict__ vel_o,
+                                                float* __restrict__ rho_o, float* __restrict__ prs_o,
+                                                uint32_t* __restrict__ idv_o, int* __restrict__ counters) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float2 p = pos[i], v = vel[i];
+    uint32_t w = idv[i];
+    int col = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
+    HaloRec r = {p.x, p.y, v.x, v.y, w};
+    if (col < send_hi_left) {
+        int k = atomicAdd(&counters[0], 1);
+        if (k < cap_left) left[k] = r;
+    }
+    if (col >= send_lo_right) {
+        int k = atomicAdd(&counters[1], 1);
+        if (k < cap_right) right[k] = r;
+    }
+    if (col >= keep_lo && col < keep_hi) {
+        int k = atomicAdd(&counters[2], 1);
+        pos_o[k] = p;
+        vel_o[k] = v;
+        rho_o[k] = rho[i];
+        prs_o[k] = prs[i];
+        idv_o[k] = w;
+    }
+}
+
+extern "C" int sphhip_pack_halo(SphCtx* c, int send_hi_left, int send_lo_right, void* d_left, int cap_left,
+                                int* n_left, void* d_right, int cap_right, int* n_right) {
+    NEED_STATE(c);
+    if (!n_left || !n_right) return fail(SPHHIP_EINVAL, "null argument");
+    if ((cap_left > 0 && !d_left) || (cap_right > 0 && !d_right)) return fail(SPHHIP_EINVAL, "null buffer");
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(int) * 4, c->stream));
+    const int n = c->n;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_split, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dc, n, c->pos, c->vel, c->rho,
+                           c->prs, c->idv, send_hi_left, send_lo_right, c->col_lo, c->col_hi, (HaloRec*)d_left,
+                           cap_left, (HaloRec*)d_right, cap_right, c->pos2, c->vel2, c->rho2, c->prs2, c->idv2,
+                           c->counters);
+        LAUNCH_CHECK();
+    }
+    int h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, c->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h[0] > cap_left || h[1] > cap_right) {
+        return fail(SPHHIP_ECAPACITY, "sphhip_pack_halo: halo buffer too small");
+    }
+    *n_left = h[0];
+    *n_right = h[1];
+    std::swap(c->pos, c->pos2);
+    std::swap(c->vel, c->vel2);
+    std::swap(c->rho, c->rho2);
+    std::swap(c->prs, c->prs2);
+    std::swap(c->idv, c->idv2);
+    c->n = h[2];
+    c->grid_valid = false;
+    c->counts_valid = false;
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_keep_columns(SphCtx* c, int lo, int hi) {
+    NEED_STATE(c);
+    int save_lo = c->col_lo, save_hi = c->col_hi;
+    c->col_lo = lo;
+    c->col_hi = hi;
+    int nl, nr;
+    int rc = sphhip_pack_halo(c, -1, 0x7fffffff, nullptr, 0, &nl, nullptr, 0, &nr);
+    c->col_lo = save_lo;
+    c->col_hi = save_hi;
+    return rc;
+}
+
+__global__ __launch_bounds__(256) void k_append(const HaloRec* __restrict__ rec, int n, int at,
+                                                 float2* __restrict__ pos, float2* __restrict__ vel,
+                                                 float* __restrict__ rho, float* __restrict__ prs,
+                                                 uint32_t* __restrict__ idv, float rest_density) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    HaloRec r = rec[i];
+    pos[at + i] = make_float2(r.x, r.y);
+    vel[at + i] = make_float2(r.vx, r.vy);
+    rho[at + i] = rest_density;
+    prs[at + i] = 0.0f;
+    idv[at + i] = r.idv;
+}
+
+extern "C" int sphhip_append(SphCtx* c, const void* d_records, int n) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    if (n < 0 || (n > 0 && !d_records)) return fail(SPHHIP_EINVAL, "sphhip_append: bad argument");
+    if (c->n + n > c->n_max) return fail(SPHHIP_ECAPACITY, "sphhip_append: exceeds the context capacity");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_append, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const HaloRec*)d_records, n,
+                           c->n, c->pos, c->vel, c->rho, c->prs, c->idv, c->params.rest_density);
+        LAUNCH_CHECK();
+    }
+    c->n += n;
+    c->have_state = true;
+    c->grid_valid = false;
+    c->counts_valid = false;
+    return SPHHIP_OK;
+}
+
+__global__ __launch_bounds__(256) void k_col_hist(DevConsts c, int n, const float2* __restrict__ pos,
+                                                   int* __restrict__ hist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    atomicAdd(&hist[sph_cell_coord(pos[i].x, c.xmin, c.inv_cell, c.nx)], 1);
+}
+
+extern "C" int sphhip_column_histogram(SphCtx* c, int* hist) {
+    NEED_STATE(c);
+    if (!hist) return fail(SPHHIP_EINVAL, "null argument");
+    // cell_start is free between steps only when the grid is stale; use keys2 as scratch instead
+    int* d_hist = (int*)c->keys2;
+    if (c->dc.nx > c->n_max) return fail(SPHHIP_ECAPACITY, "sphhip_column_histogram: nx exceeds scratch");
+    HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(int) * (size_t)c->dc.nx, c->stream));
+    if (c->n > 0) {
+        hipLaunchKernelGGL(k_col_hist, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->dc, c->n, c->pos, d_hist);
+        LAUNCH_CHECK();
+    }
+    HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(int) * (size_t)c->dc.nx, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPHHIP_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------------
+extern "C" int sphhip_set_profiling(SphCtx* c, int enable) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    timer_flush(c);
+    c->profiling = enable != 0;
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_get_phase_times(SphCtx* c, float* ms, int* launches) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    timer_flush(c);
+    for (int ph = 0; ph < SPHHIP_PH_COUNT; ph++) {
+        if (ms) ms[ph] = (float)c->timer.ms[ph];
+        if (launches) launches[ph] = (int)c->timer.launches[ph];
+    }
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_reset_phase_times(SphCtx* c) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    timer_flush(c);
+    for (int ph = 0; ph < SPHHIP_PH_COUNT; ph++) {
+        c->timer.ms[ph] = 0;
+        c->timer.launches[ph] = 0;
+    }
+    return SPHHIP_OK;
+}

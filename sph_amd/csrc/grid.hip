@@ -1,0 +1,404 @@
+// grid.hip -- uniform-grid cell list for gfx950: cell hash, LDS-local LSD radix sort, monotone
+// cell start array, in-cell id ranking and the reorder of the SoA state into (key, id) order.
+//
+// There is no reference code for this phase: the reference only names `int* grid, int* cellStart,
+// int* cellEnd` as dead kernel parameters (SPH/sph.cuh:33-34,38; always nullptr, SPH/sph.cu:222-223).
+// The spec (shared with oracle/sph_oracle.c, orc_build_cells) is:
+//   cx = clamp((int)floorf((x - xmin) * inv_cell), 0, nx-1), cy likewise, key = cx * ny + cy
+//   sorted order = ascending (key, id);  cell_start[k] = #{particles with key < k}, k = 0..ncell
+// All of it is HBM-bound integer work: coalesced 4/8-byte streams, LDS for the per-tile ranking.
+#include "sphhip_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// cell hash: key per slot + identity permutation.   R pos 8 B, W key 4 B + idx 4 B per particle
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hash(DevConsts c, const float2* __restrict__ pos, int n,
+                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float2 p = pos[i];
+    int cx = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
+    int cy = sph_cell_coord(p.y, c.ymin, c.inv_cell, c.ny);
+    keys[i] = (uint32_t)(cx * c.ny + cy);
+    perm[i] = (uint32_t)i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Radix sort pass, kernel 1: per-workgroup digit histogram, stored digit-major
+// (block_hist[d * nblocks + b]) so that kernel 2 scans contiguous rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys, int n, int shift,
+                                                             uint32_t mask, int* __restrict__ block_hist,
+                                                             int nblocks) {
+    __shared__ int hist[SORT_RADIX];
+    int tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    int base = blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        int idx = base + r * SORT_THREADS + tid;
+        if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & mask], 1);
+    }
+    __syncthreads();
+    block_hist[tid * nblocks + blockIdx.x] = hist[tid];
+}
+
+// Exclusive scan of 256 values, one per thread of a 256-thread workgroup.
+__device__ __forceinline__ int block_excl_scan_256(int v, int* lds_wave /*[4]*/, int* total) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) lds_wave[wave] = incl;
+    __syncthreads();
+    int w0 = lds_wave[0], w1 = lds_wave[1], w2 = lds_wave[2], w3 = lds_wave[3];
+    int off = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    if (total) *total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return off + incl - v;
+}
+
+// Kernel 2a: workgroup d scans row d of block_hist in place (exclusive) and stores the row total.
+__global__ __launch_bounds__(256) void k_sort_scan_rows(int* __restrict__ block_hist, int nblocks,
+                                                         int* __restrict__ digit_total) {
+    __shared__ int lds_wave[4];
+    int* row = block_hist + (size_t)blockIdx.x * nblocks;
+    int carry = 0;
+    for (int base = 0; base < nblocks; base += 256) {
+        int i = base + (int)threadIdx.x;
+        int v = (i < nblocks) ? row[i] : 0;
+        int tot;
+        int ex = block_excl_scan_256(v, lds_wave, &tot);
+        if (i < nblocks) row[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+}
+
+// Kernel 2b: exclusive scan of the 256 digit totals -> digit_total[256 + d] = global base of digit d.
+__global__ __launch_bounds__(256) void k_sort_scan_digits(int* __restrict__ digit_total) {
+    __shared__ int lds_wave[4];
+    int v = digit_total[threadIdx.x];
+    int ex = block_excl_scan_256(v, lds_wave, nullptr);
+    digit_total[SORT_RADIX + threadIdx.x] = ex;
+}
+
+// Kernel 3: stable LDS-local ranking of the tile by digit, then a run-coalesced scatter.
+// Stability (needed by the LSD passes) follows from ranking items in index order: rounds in
+// order, waves in order inside a round, lanes in order inside a wave.
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* __restrict__ keys_in,
+                                                                const uint32_t* __restrict__ vals_in,
+                                                                uint32_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ vals_out, int n, int shift,
+                                                                uint32_t mask, const int* __restrict__ block_hist,
+                                                                const int* __restrict__ digit_total, int nblocks) {
+    __shared__ unsigned short cnt[SORT_ITEMS][4][SORT_RADIX];  // 16 KB
+    __shared__ int digit_start[SORT_RADIX];
+    __shared__ int global_off[SORT_RADIX];
+    __shared__ int lds_wave[4];
+    __shared__ uint2 stage[SORT_TILE];  // 16 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = blockIdx.x * SORT_TILE;
+    const int tile_n = min(SORT_TILE, n - base);
+
+    {  // zero the counters: 8*4*256 shorts = 4096 ints
+        int* z = reinterpret_cast<int*>(&cnt[0][0][0]);
+#pragma unroll
+        for (int i = 0; i < (SORT_ITEMS * 4 * SORT_RADIX / 2) / SORT_THREADS; i++) z[i * SORT_THREADS + tid] = 0;
+    }
+    __syncthreads();
+
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
+    int rank_in_wave[SORT_ITEMS];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        int idx = base + r * SORT_THREADS + tid;
+        bool ok = idx < n;
+        key[r] = ok ? keys_in[idx] : 0xffffffffu;
+        val[r] = ok ? vals_in[idx] : 0u;
+        uint32_t d = (key[r] >> shift) & mask;
+        // lanes of this wave holding the same digit (and the same in-range status)
+        unsigned long long peers = __ballot(ok) ^ (ok ? 0ull : ~0ull);  // ok lanes: ballot(ok); others: ~ballot(ok)
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            unsigned long long bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        rank_in_wave[r] = __popcll(peers & lt_mask);
+        if (ok && rank_in_wave[r] == 0) cnt[r][wave][d] = (unsigned short)__popcll(peers);
+    }
+    __syncthreads();
+
+    {  // thread d: exclusive prefix of digit d's counts over (round, wave); then the digit bases
+        int running = 0;
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; r++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                int cval = cnt[r][w][tid];
+                cnt[r][w][tid] = (unsigned short)running;
+                running += cval;
+            }
+        int ex = block_excl_scan_256(running, lds_wave, nullptr);
+        digit_start[tid] = ex;
+        global_off[tid] = digit_total[SORT_RADIX + tid] + block_hist[(size_t)tid * nblocks + blockIdx.x] - ex;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        int idx = base + r * SORT_THREADS + tid;
+        if (idx < n) {
+            uint32_t d = (key[r] >> shift) & mask;
+            int p = digit_start[d] + (int)cnt[r][wave][d] + rank_in_wave[r];
+            stage[p] = make_uint2(key[r], val[r]);
+        }
+    }
+    __syncthreads();
+
+    for (int p = tid; p < tile_n; p += SORT_THREADS) {
+        uint2 kv = stage[p];
+        int dst = global_off[(kv.x >> shift) & mask] + p;
+        keys_out[dst] = kv.x;
+        vals_out[dst] = kv.y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cell marks: mark[k] = first sorted slot holding key k (array pre-filled with 0x7f7f7f7f), and
+// the particle ids in sorted-slot order for the in-cell ranking.  R key 4+4, perm 4, id 4; W 4+4.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cell_marks(const uint32_t* __restrict__ skeys,
+                                                     const uint32_t* __restrict__ perm,
+                                                     const uint32_t* __restrict__ idv, int n,
+                                                     int* __restrict__ cell_start,
+                                                     uint32_t* __restrict__ ids_sorted) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    uint32_t k = skeys[s];
+    if (s == 0 || skeys[s - 1] != k) cell_start[k] = s;
+    ids_sorted[s] = idv[perm[s]] & SPH_ID_MASK;
+}
+
+// Suffix-min scan over the ncell+1 marks -> monotone cell_start (empty cells inherit the start of
+// the next non-empty cell).  Three small kernels: chunk minima, suffix-min of the chunk minima
+// (one workgroup), apply.  Chunk = 2048 cells.
+constexpr int SCAN_CHUNK = 2048;
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_sufmin_reduce(const int* __restrict__ a, int len, int* __restrict__ part) {
+    __shared__ int w[4];
+    int base = blockIdx.x * SCAN_CHUNK;
+    int m = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < SCAN_CHUNK / 256; r++) {
+        int i = base + r * 256 + (int)threadIdx.x;
+        if (i < len) m = min(m, a[i]);
+    }
+    m = wave_min(m);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = min(min(w[0], w[1]), min(w[2], w[3]));
+}
+
+// part[b] <- min(part[b+1 ..]) (exclusive suffix min); single workgroup, sequential over 256-chunks
+// from the back.
+__global__ __launch_bounds__(256) void k_sufmin_parts(int* __restrict__ part, int nparts) {
+    __shared__ int buf[256];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0x7fffffff;
+    __syncthreads();
+    int nchunks = (nparts + 255) / 256;
+    for (int ch = nchunks - 1; ch >= 0; ch--) {
+        int i = ch * 256 + (int)threadIdx.x;
+        int v = (i < nparts) ? part[i] : 0x7fffffff;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        // inclusive suffix min within the chunk (Hillis-Steele, 8 steps)
+        for (int d = 1; d < 256; d <<= 1) {
+            int o = (threadIdx.x + d < 256) ? buf[threadIdx.x + d] : 0x7fffffff;
+            __syncthreads();
+            buf[threadIdx.x] = min(buf[threadIdx.x], o);
+            __syncthreads();
+        }
+        int carry = carry_s;
+        int excl = (threadIdx.x + 1 < 256) ? buf[threadIdx.x + 1] : 0x7fffffff;
+        int chunk_min = buf[0];
+        __syncthreads();
+        if (i < nparts) part[i] = min(excl, carry);
+        if (threadIdx.x == 0) carry_s = min(carry, chunk_min);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sufmin_apply(int* __restrict__ a, int len, const int* __restrict__ part,
+                                                       int n) {
+    __shared__ int buf[SCAN_CHUNK];
+    __shared__ int wmin[4];
+    int base = blockIdx.x * SCAN_CHUNK;
+    int tid = threadIdx.x;
+    // thread t owns the 8 consecutive cells base + 8t .. base + 8t + 7
+    int v[8];
+    int m = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int i = base + r * 256 + tid;  // coalesced load into LDS
+        buf[r * 256 + tid] = (i < len) ? a[i] : 0x7fffffff;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 7; r >= 0; r--) {
+        m = min(m, buf[tid * 8 + r]);
+        v[r] = m;  // inclusive suffix min within the thread's 8 cells
+    }
+    // exclusive suffix min across threads: wave level then workgroup level
+    int lane = tid & 63, wave = tid >> 6;
+    int incl = m;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_down(incl, d, 64);
+        if (lane + d < 64) incl = min(incl, t);
+    }
+    if (lane == 0) wmin[wave] = incl;
+    int excl_in_wave = __shfl_down(incl, 1, 64);
+    if (lane == 63) excl_in_wave = 0x7fffffff;
+    __syncthreads();
+    int after = part[blockIdx.x];
+    for (int w = 3; w > wave; w--) after = min(after, wmin[w]);
+    int excl = min(excl_in_wave, after);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++) buf[tid * 8 + r] = min(min(v[r], excl), n);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int i = base + r * 256 + tid;
+        if (i < len) a[i] = buf[r * 256 + tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// In-cell ranking by id + reorder.  The LSD sort leaves ties (same cell) in the order of the
+// previous step; ranking each particle among its cell-mates by id makes the order canonical
+// (key, id) whatever the input order was -- which is what makes results independent of history,
+// of the slab partition and of the arrival order of migrated particles.
+// R: key 4, cell_start 8, ids ~cell size * 4 (cached), perm 4, state 16|24 + idv 4;  W: 16|24 + 4.
+// ---------------------------------------------------------------------------------------------
+template <bool CARRY_DENSITY>
+__global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict__ skeys,
+                                                       const uint32_t* __restrict__ perm,
+                                                       const uint32_t* __restrict__ ids_sorted,
+                                                       const int* __restrict__ cell_start, int n,
+                                                       const float2* __restrict__ pos, const float2* __restrict__ vel,
+                                                       const float* __restrict__ rho, const float* __restrict__ prs,
+                                                       const uint32_t* __restrict__ idv, float2* __restrict__ pos_o,
+                                                       float2* __restrict__ vel_o, float* __restrict__ rho_o,
+                                                       float* __restrict__ prs_o, uint32_t* __restrict__ idv_o) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    uint32_t k = skeys[s];
+    int a = cell_start[k], b = cell_start[k + 1];
+    uint32_t my = ids_sorted[s];
+    int rank = 0;
+    for (int t = a; t < b; t++) rank += (ids_sorted[t] < my) ? 1 : 0;
+    int dst = a + rank;
+    uint32_t src = perm[s];
+    pos_o[dst] = pos[src];
+    vel_o[dst] = vel[src];
+    if (CARRY_DENSITY) {
+        rho_o[dst] = rho[src];
+        prs_o[dst] = prs[src];
+    }
+    idv_o[dst] = idv[src];
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline int ilog2_ceil(unsigned v) {
+    int b = 0;
+    while ((1u << b) < v && b < 31) b++;
+    return b;
+}
+
+int sph_grid_build(SphCtx* c, bool carry_density) {
+    const int n = c->n;
+    hipStream_t st = c->stream;
+    const int ncell = c->ncell;
+    if (n > 0) {
+        {
+            PhaseScope ps(c, SPHHIP_PH_HASH);
+            hipLaunchKernelGGL(k_hash, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, n, c->keys, c->perm);
+            LAUNCH_CHECK();
+        }
+        {
+            PhaseScope ps(c, SPHHIP_PH_SORT);
+            int key_bits = ilog2_ceil((unsigned)ncell);
+            if (key_bits < 1) key_bits = 1;
+            int passes = (key_bits + 7) / 8;
+            int bits_per_pass = (key_bits + passes - 1) / passes;
+            int nblocks = (n + SORT_TILE - 1) / SORT_TILE;
+            int shift = 0;
+            for (int p = 0; p < passes; p++) {
+                int bits = min(bits_per_pass, key_bits - shift);
+                uint32_t mask = (1u << bits) - 1u;
+                hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(SORT_THREADS), 0, st, c->keys, n, shift, mask,
+                                   c->block_hist, nblocks);
+                hipLaunchKernelGGL(k_sort_scan_rows, dim3(SORT_RADIX), dim3(256), 0, st, c->block_hist, nblocks,
+                                   c->digit_total);
+                hipLaunchKernelGGL(k_sort_scan_digits, dim3(1), dim3(256), 0, st, c->digit_total);
+                hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(SORT_THREADS), 0, st, c->keys, c->perm,
+                                   c->keys2, c->perm2, n, shift, mask, c->block_hist, c->digit_total, nblocks);
+                LAUNCH_CHECK();
+                std::swap(c->keys, c->keys2);
+                std::swap(c->perm, c->perm2);
+                shift += bits;
+            }
+        }
+    }
+    {
+        PhaseScope ps(c, SPHHIP_PH_CELLS);
+        const int len = ncell + 1;
+        HIP_TRY(hipMemsetAsync(c->cell_start, 0x7f, sizeof(int) * (size_t)len, st));
+        if (n > 0) {
+            hipLaunchKernelGGL(k_cell_marks, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm, c->idv, n,
+                               c->cell_start, c->ids_sorted);
+        }
+        int nparts = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        hipLaunchKernelGGL(k_sufmin_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp);
+        hipLaunchKernelGGL(k_sufmin_parts, dim3(1), dim3(256), 0, st, c->scan_tmp, nparts);
+        hipLaunchKernelGGL(k_sufmin_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp, n);
+        LAUNCH_CHECK();
+    }
+    if (n > 0) {
+        PhaseScope ps(c, SPHHIP_PH_REORDER);
+        if (carry_density)
+            hipLaunchKernelGGL(k_rank_reorder<true>, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm,
+                               c->ids_sorted, c->cell_start, n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
+                               c->vel2, c->rho2, c->prs2, c->idv2);
+        else
+            hipLaunchKernelGGL(k_rank_reorder<false>, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm,
+                               c->ids_sorted, c->cell_start, n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
+                               c->vel2, c->rho2, c->prs2, c->idv2);
+        LAUNCH_CHECK();
+        std::swap(c->pos, c->pos2);
+        std::swap(c->vel, c->vel2);
+        if (carry_density) {
+            std::swap(c->rho, c->rho2);
+            std::swap(c->prs, c->prs2);
+        }
+        std::swap(c->idv, c->idv2);
+    }
+    c->grid_valid = true;
+    c->counts_valid = false;
+    return SPHHIP_OK;
+}

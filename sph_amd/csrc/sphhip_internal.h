@@ -1,0 +1,141 @@
+// sphhip_internal.h -- shared declarations of libsphhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/sphhip.h"
+
+// ---------------------------------------------------------------------------------------------
+// Constants handed to every kernel by value.  All folded on the host with the reference's
+// expression order (sphhip_derive); kernels never call powf.
+// ---------------------------------------------------------------------------------------------
+struct DevConsts {
+    float h, h2, poly6, spiky, visc_lap, visc_mass, neg_mass, lj_cut, lj24, sigma, mass;
+    float stiffness, rest_density, gravity, force_cap, mouse_radius, mouse_r2;
+    float dt, max_vel, damping;
+    float xmin, xmax, ymin, ymax;
+    float inv_cell;
+    int nx, ny;
+};
+
+// idv word: particle id in bits 0..30, bit 31 set when the reference's `valid` flag is false.
+#define SPH_INVALID_BIT 0x80000000u
+#define SPH_ID_MASK 0x7fffffffu
+
+// ---- radix sort geometry --------------------------------------------------------------------
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 8;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 2048 keys per workgroup
+constexpr int SORT_RADIX = 256;
+
+// ---- pair-kernel geometry -------------------------------------------------------------------
+constexpr int PAIR_THREADS = 256;
+constexpr int PAIR_MAX_TILE_CELLS = 64;  // cells of one column per workgroup (runtime <= this)
+
+struct PhaseTimer {
+    std::vector<hipEvent_t> start[SPHHIP_PH_COUNT], stop[SPHHIP_PH_COUNT];
+    size_t used[SPHHIP_PH_COUNT] = {0};
+    double ms[SPHHIP_PH_COUNT] = {0};
+    long launches[SPHHIP_PH_COUNT] = {0};
+};
+
+struct SphCtx {
+    SphParams params;
+    SphDerived drv;
+    DevConsts dc;
+    int device = 0;
+    int n_max = 0;   // particle capacity
+    int n = 0;       // particles currently held
+    int ncell = 0;   // nx * ny
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool have_state = false;
+    bool grid_valid = false;
+    bool counts_valid = false;
+    int col_lo = 0, col_hi = 0;  // owned columns (default: all)
+    int tile_cells = 16;         // cells of a column per pair-kernel workgroup
+    int pair_cap = 1536;         // neighbour candidates staged in LDS per workgroup
+
+    // state, SoA, all in the same (slot) order
+    float2 *pos = nullptr, *vel = nullptr, *pos2 = nullptr, *vel2 = nullptr;
+    float *rho = nullptr, *prs = nullptr, *rho2 = nullptr, *prs2 = nullptr;
+    uint32_t *idv = nullptr, *idv2 = nullptr;
+    int* ncount = nullptr;  // neighbour counts of the last density pass (slot order)
+
+    // grid
+    uint32_t *keys = nullptr, *keys2 = nullptr;  // cell key per slot (ping-pong during the sort)
+    uint32_t *perm = nullptr, *perm2 = nullptr;  // source slot per sorted slot
+    uint32_t* ids_sorted = nullptr;              // id per sorted slot before the in-cell id ranking
+    int* cell_start = nullptr;                   // ncell + 1, monotone
+    int* block_hist = nullptr;                   // SORT_RADIX * nblocks
+    int* digit_total = nullptr;                  // SORT_RADIX (+ SORT_RADIX bases)
+    int* scan_tmp = nullptr;                     // block partials of the suffix-min scan
+    int* counters = nullptr;                     // small device scratch (compaction counters ...)
+    void* staging = nullptr;                     // AoS staging for upload / download (28 B * n_max)
+
+    bool profiling = false;
+    PhaseTimer timer;
+};
+
+// ---- error plumbing -------------------------------------------------------------------------
+void sph_set_error(const std::string& msg);
+int sph_hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define HIP_TRY(call)                                                        \
+    do {                                                                     \
+        hipError_t _e = (call);                                              \
+        if (_e != hipSuccess) return sph_hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define LAUNCH_CHECK()                                                       \
+    do {                                                                     \
+        hipError_t _e = hipGetLastError();                                   \
+        if (_e != hipSuccess) return sph_hip_fail(_e, "kernel launch", __FILE__, __LINE__); \
+    } while (0)
+
+// ---- phase implementations (each enqueues on ctx->stream and returns) -----------------------
+int sph_grid_build(SphCtx* c, bool carry_density);
+int sph_density_launch(SphCtx* c);
+int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate);
+int sph_integrate_launch(SphCtx* c);
+int sph_unpack_aos(SphCtx* c, int n, int id_base);
+int sph_pack_aos(SphCtx* c, int n, uint32_t* d_ids_out);
+
+// phase timing helpers
+void sph_phase_begin(SphCtx* c, int ph);
+void sph_phase_end(SphCtx* c, int ph);
+
+struct PhaseScope {
+    SphCtx* c;
+    int ph;
+    PhaseScope(SphCtx* c_, int ph_) : c(c_), ph(ph_) { sph_phase_begin(c, ph); }
+    ~PhaseScope() { sph_phase_end(c, ph); }
+};
+
+// ---- small device helpers -------------------------------------------------------------------
+__device__ __forceinline__ int sph_lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Cell coordinate of x: clamp((int)floorf((x - x0) * inv_cell), 0, n - 1); NaN -> 0.
+__device__ __forceinline__ int sph_cell_coord(float x, float x0, float inv_cell, int n) {
+    float f = floorf((x - x0) * inv_cell);
+    int c;
+    if (!(f >= 0.0f))
+        c = 0;
+    else if (f >= (float)n)
+        c = n - 1;
+    else
+        c = (int)f;
+    return c;
+}
+
+// XCD-aware workgroup remap (bijective for any grid size): workgroups b and b+8 share an XCD
+// under round-robin dispatch, so give each XCD a contiguous run of logical tiles -- neighbouring
+// tiles (which share neighbour-column data) then hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ int sph_xcd_remap(int b, int nb) {
+    int xcd = b & 7, q = nb >> 3, r = nb & 7;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}

@@ -1,0 +1,95 @@
+"""ctypes binding of libsphhip.so (include/sphhip.h).  There is no CPU fallback: if the HIP
+library is missing this module raises at import of the symbol table, and every compute call needs
+a GPU."""
+import ctypes
+import os
+
+from .params import SphDerived, SphParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsphhip.so")
+
+PH_NAMES = ["hash", "sort", "cells", "reorder", "density", "force", "integrate"]
+
+_vp = ctypes.c_void_p
+_ci = ctypes.c_int
+_cf = ctypes.c_float
+_pi = ctypes.POINTER(ctypes.c_int)
+
+# name -> argtypes; every function returns int except sphhip_last_error
+SIGNATURES = {
+    "sphhip_default_params": [ctypes.POINTER(SphParams)],
+    "sphhip_derive": [ctypes.POINTER(SphParams), ctypes.POINTER(SphDerived)],
+    "sphhip_create": [ctypes.POINTER(SphParams), _ci, _ci, ctypes.POINTER(_vp)],
+    "sphhip_destroy": [_vp],
+    "sphhip_set_stream": [_vp, _vp],
+    "sphhip_get_stream": [_vp, ctypes.POINTER(_vp)],
+    "sphhip_synchronize": [_vp],
+    "sphhip_set_tuning": [_vp, _ci, _ci],
+    "sphhip_upload": [_vp, _vp, _ci, _ci],
+    "sphhip_download": [_vp, _vp, _ci],
+    "sphhip_download_ids": [_vp, _vp, _vp, _ci],
+    "sphhip_count": [_vp, _pi],
+    "sphhip_build_grid": [_vp],
+    "sphhip_density": [_vp],
+    "sphhip_forces": [_vp, _cf, _cf, _cf],
+    "sphhip_integrate": [_vp],
+    "sphhip_step": [_vp, _cf, _cf, _cf, _ci],
+    "sphhip_get_cells": [_vp, _vp, _vp, _vp, _vp],
+    "sphhip_get_neighbor_counts": [_vp, _vp, _ci],
+    "sphhip_set_owned_columns": [_vp, _ci, _ci],
+    "sphhip_pack_halo": [_vp, _ci, _ci, _vp, _ci, _pi, _vp, _ci, _pi],
+    "sphhip_keep_columns": [_vp, _ci, _ci],
+    "sphhip_append": [_vp, _vp, _ci],
+    "sphhip_column_histogram": [_vp, _vp],
+    "sphhip_set_profiling": [_vp, _ci],
+    "sphhip_get_phase_times": [_vp, _vp, _vp],
+    "sphhip_reset_phase_times": [_vp],
+    "sphhip_get_pair_count": [_vp, ctypes.POINTER(ctypes.c_longlong)],
+}
+
+
+class SphHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads libsphhip.so (built in-tree by `make -C sph_amd/csrc`); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SphHipError(
+            "sph_amd/libsphhip.so is missing: build it with `make -C sph_amd/csrc` "
+            "(or __graft_entry__.build()). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.sphhip_last_error.restype = ctypes.c_char_p
+    lib.sphhip_last_error.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().sphhip_last_error()
+        raise SphHipError("sphhip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def derive(params):
+    d = SphDerived()
+    check(load().sphhip_derive(ctypes.byref(params), ctypes.byref(d)))
+    return d
+
+
+def default_params():
+    p = SphParams()
+    check(load().sphhip_default_params(ctypes.byref(p)))
+    return p

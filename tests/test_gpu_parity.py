@@ -1,0 +1,246 @@
+"""Parity of the HIP path (through the C ABI, libsphhip.so) against the CPU oracle and the golden
+vectors generated from the reference's own serial step.
+
+Bars:
+  * integer work -- cell keys, sorted order, cell start/end, neighbour counts: bit-exact;
+  * floating point vs the oracle's cell-list functions (same per-particle summation order,
+    snapshot velocity semantics): bit-exact -- the kernels evaluate the reference's expressions
+    in IEEE binary32 without contraction;
+  * floating point vs the reference's serial path (all-pairs j order, Gauss-Seidel velocity
+    update, SPH/sph.cpp:96-97): stated tolerances below (summation order + snapshot semantics).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from sph_amd import scenes
+from sph_amd.params import PARTICLE_DTYPE, SphParams
+from sph_amd.solver import Solver
+
+pytestmark = pytest.mark.gpu
+
+O = orc.Oracle()
+P = O.default_params()
+
+
+def G(name):
+    return np.load(os.path.join(orc.GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def random_state(n, lo, hi, seed, vel=1.0, invalid=0.0):
+    rng = np.random.default_rng(seed)
+    a = np.zeros(n, PARTICLE_DTYPE)
+    a["pos"] = rng.uniform(lo, hi, (n, 2)).astype(np.float32)
+    a["vel"] = rng.normal(0, vel, (n, 2)).astype(np.float32)
+    a["density"] = 1000.0
+    a["valid"] = rng.random(n) >= invalid
+    return a
+
+
+@pytest.fixture(scope="module")
+def solver():
+    s = Solver(P, n_max=1 << 16)
+    yield s
+    s.close()
+
+
+def test_roundtrip(solver):
+    a = random_state(5000, 0.05, 1.95, 1, invalid=0.1)
+    a["density"] = np.random.default_rng(2).uniform(1, 2000, len(a)).astype(np.float32)
+    a["pressure"] = np.random.default_rng(3).uniform(0, 1e5, len(a)).astype(np.float32)
+    solver.upload(a)
+    assert solver.n == len(a)
+    assert orc.same_bits(solver.download(), a)
+    solver.buildNeighbors()  # reorders internally; must stay invisible
+    assert orc.same_bits(solver.download(), a)
+
+
+def test_integrate_walls_golden(solver):
+    g = G("f7_walls")
+    solver.upload(g["state"])
+    solver.integrate()
+    assert orc.same_bits(solver.download(), g["after_integrate"])
+
+
+@pytest.mark.parametrize("n,lo,hi,seed", [(1, 0.5, 0.6, 0), (2, 0.5, 0.6, 1), (777, 0.05, 1.95, 2), (4096, 0.05, 1.95, 3),
+                                          (3000, 0.9, 1.1, 4), (50000, 0.05, 1.95, 5)])
+def test_cells_bit_exact(solver, n, lo, hi, seed):
+    a = random_state(n, lo, hi, seed)
+    solver.upload(a)
+    solver.buildNeighbors()
+    keys, order, cs, ce = solver.cells()
+    okeys, oorder, oskeys, ocs = O.build_cells(P, a)
+    assert np.array_equal(keys, oskeys)
+    assert np.array_equal(order, oorder)
+    assert np.array_equal(cs, ocs[:-1])
+    assert np.array_equal(ce, ocs[1:])
+
+
+def test_cells_after_shuffled_history(solver):
+    """The sorted order must be canonical (key, id) whatever order the state was in before."""
+    a = scenes.lattice(4096)
+    solver.upload(a)
+    solver.stepSimulation(nsteps=3)  # internal order is now the order of an earlier sort
+    b = solver.download()
+    solver.buildNeighbors()
+    keys, order, cs, ce = solver.cells()
+    okeys, oorder, oskeys, ocs = O.build_cells(P, b)
+    assert np.array_equal(keys, oskeys) and np.array_equal(order, oorder)
+    assert np.array_equal(cs, ocs[:-1]) and np.array_equal(ce, ocs[1:])
+
+
+@pytest.mark.parametrize("name,key", [("f2_serial_traj_n1024", "s1"), ("f2_serial_traj_n1024", "s100"),
+                                      ("f5_dense_block", "state")])
+def test_density_and_counts(solver, name, key):
+    a = G(name)[key].copy()
+    solver.upload(a)
+    solver.computeDensityPressure()
+    got = solver.download()
+    want, cnt = O.density_cells(P, a.copy())
+    assert orc.same_bits(got, want)  # bit-exact vs oracle (same summation order)
+    counts = solver.neighbor_counts()
+    assert np.array_equal(counts, cnt)
+    gk = {"s1": "n1024_s1", "s100": "n1024_s100", "state": "dense"}[key]
+    assert np.array_equal(counts, G("f8_neighbor_counts")[gk])  # reference predicate, all pairs
+    # vs the reference's all-pairs sum: summation order only.  rel tol 4e-6 (fp32, <= ~500 terms)
+    ref = O.density_allpairs(P, a.copy())
+    assert np.allclose(got["density"], ref["density"], rtol=4e-6, atol=0)
+
+
+@pytest.mark.parametrize("mouse,strength", [((0.0, 0.0), 0.0), ((1.0, 1.0), 50000.0), ((0.7, 1.3), -50000.0)])
+def test_forces_bit_exact_vs_oracle(solver, mouse, strength):
+    for a in (G("f4_phases_n1024")["after_density"], G("f5_dense_block")["after_density"],
+              G("f9_invalid")["state"]):
+        solver.upload(a)
+        solver.computeForces(mouse, strength)
+        got = solver.download()
+        want = O.forces_cells(P, a.copy(), mouse, strength)
+        assert orc.same_bits(got, want)
+
+
+def test_forces_vs_reference_serial_golden(solver):
+    """One force pass against the reference's serial output.  Differences: j-summation order and
+    Gauss-Seidel vs snapshot neighbour velocities.  Acceleration = dv/DT; tolerance relative to the
+    largest acceleration in the scene (the pair terms nearly cancel on a lattice)."""
+    g = G("f4_phases_n1024")
+    solver.upload(g["after_density"])
+    solver.computeForces()
+    got = solver.download()
+    dt = np.float32(0.0005)
+    acc_got = (got["vel"] - g["after_density"]["vel"]) / dt
+    acc_ref = (g["after_forces"]["vel"] - g["after_density"]["vel"]) / dt
+    scale = np.abs(acc_ref).max()
+    # vs serial (Gauss-Seidel velocities, sph.cpp:96-97): the viscosity term sees updated v_j for j < i
+    assert np.abs(acc_got - acc_ref).max() <= 1e-3 * scale
+    # vs the same all-pairs sum with snapshot velocities (MPI_sph.cpp semantics): summation order only
+    snap = O.forces_allpairs(P, g["after_density"].copy(), flags=orc.SNAPSHOT)
+    acc_snap = (snap["vel"] - g["after_density"]["vel"]) / dt
+    assert np.abs(acc_got - acc_snap).max() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("n,steps", [(1024, 10), (1000, 3), (2704, 2), (4096, 3)])
+def test_step_bit_exact_vs_oracle(solver, n, steps):
+    a = scenes.lattice(n)
+    solver.upload(a)
+    solver.stepSimulation(nsteps=steps)
+    got = solver.download()
+    want = O.step_cells(P, a.copy(), steps)
+    assert orc.same_bits(got, want)
+
+
+def test_phases_equal_fused_step(solver):
+    a = G("f2_serial_traj_n1024")["s50"]
+    solver.upload(a)
+    solver.stepSimulation((0.8, 0.9), 50000.0, 4)
+    fused = solver.download()
+    solver.upload(a)
+    for _ in range(4):
+        solver.buildNeighbors()
+        solver.computeDensityPressure()
+        solver.computeForces((0.8, 0.9), 50000.0)
+        solver.integrate()
+    assert orc.same_bits(solver.download(), fused)
+
+
+def test_trajectory_vs_reference_serial_golden(solver):
+    """N-step parity with the reference's serial path on its default scene (N=1024, main.cpp:68).
+    Stated tolerance (fp32; snapshot-vs-Gauss-Seidel gap dominates):
+      10 steps : |dx| <= 2.4e-7 (2 ulp at x~2), |dv| <= 5e-5, density rel 5e-6
+      100 steps: |dx| <= 2e-5,  |dv| <= 1e-3 (v_max 0.55),  density rel 1e-4
+    Measured with the oracle (bit-identical to the HIP path): 1.2e-7 / 2.2e-5 / 1.3e-6 at 10 steps,
+    5.8e-6 / 2.2e-4 / 4.4e-5 at 100 steps.
+    """
+    g = G("f2_serial_traj_n1024")
+    solver.upload(g["s0"])
+    solver.stepSimulation(nsteps=10)
+    s10 = solver.download()
+    assert np.abs(s10["pos"] - g["s10"]["pos"]).max() <= 2.4e-7
+    assert np.abs(s10["vel"] - g["s10"]["vel"]).max() <= 5e-5
+    assert np.allclose(s10["density"], g["s10"]["density"], rtol=5e-6)
+    solver.stepSimulation(nsteps=90)
+    s100 = solver.download()
+    assert np.abs(s100["pos"] - g["s100"]["pos"]).max() <= 2e-5
+    assert np.abs(s100["vel"] - g["s100"]["vel"]).max() <= 1e-3
+    assert np.allclose(s100["density"], g["s100"]["density"], rtol=1e-4)
+    # and bit-exact against the snapshot-semantics oracle in the GPU's summation order
+    want = O.step_cells(P, g["s0"].copy(), 100)
+    assert orc.same_bits(s100, want)
+
+
+def test_invalid_particles_golden(solver):
+    g = G("f9_invalid")
+    solver.upload(g["state"])
+    solver.stepSimulation(nsteps=1)
+    got = solver.download()
+    inv = g["state"]["valid"] == 0
+    # invalid particles keep position and velocity (sph.cpp:59,103) -- bit-exact
+    assert np.array_equal(got["pos"][inv], g["state"]["pos"][inv])
+    assert np.array_equal(got["vel"][inv], g["state"]["vel"][inv])
+    assert np.array_equal(got["valid"], g["state"]["valid"])
+    assert np.abs(got["pos"] - g["after_1step"]["pos"]).max() <= 1.2e-7
+    assert np.abs(got["vel"] - g["after_1step"]["vel"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("tile_cells,cap", [(1, 64), (3, 200), (16, 1536), (64, 6144), (5, 64)])
+def test_tuning_does_not_change_results(solver, tile_cells, cap):
+    """Tile height and LDS budget (including the global-memory fallback when a tile's candidates
+    exceed the budget) must not change a single bit."""
+    a = G("f5_dense_block")["state"]
+    want = O.step_cells(P, a.copy(), 2)
+    solver.set_tuning(tile_cells, cap)
+    try:
+        solver.upload(a)
+        solver.stepSimulation(nsteps=2)
+        assert orc.same_bits(solver.download(), want)
+    finally:
+        solver.set_tuning(16, 1536)
+
+
+def test_empty_and_tiny(solver):
+    solver.upload(np.zeros(0, PARTICLE_DTYPE))
+    solver.stepSimulation(nsteps=2)
+    assert solver.n == 0
+    for n in (1, 2, 3):
+        a = scenes.lattice(n)
+        solver.upload(a)
+        solver.stepSimulation(nsteps=3)
+        assert orc.same_bits(solver.download(), O.step_cells(P, a.copy(), 3))
+
+
+def test_scaled_scene_miniatures():
+    """Miniatures of the bench scenes (same spacing H/4, scaled walls): bit-exact vs the oracle,
+    neighbour counts vs the all-pairs reference predicate."""
+    for params, a in (scenes.dam_break(48), scenes.uniform_box(56)):
+        with Solver(params, n_max=len(a)) as s:
+            s.upload(a)
+            s.computeDensityPressure()
+            assert np.array_equal(s.neighbor_counts(), O.neighbor_counts_allpairs(params, a))
+            s.upload(a)
+            s.stepSimulation(nsteps=5)
+            got = s.download()
+        want = O.step_cells(params, a.copy(), 5)
+        assert orc.same_bits(got, want)
+        ref = O.step_allpairs(params, a.copy(), 5, flags=orc.GAUSS_SEIDEL)  # reference serial semantics
+        assert np.abs(got["pos"] - ref["pos"]).max() <= 1e-6
