@@ -32,10 +32,9 @@ struct TileGeom {
     int total;
 };
 
-__device__ __forceinline__ void tile_geometry(const DevConsts& c, const int* __restrict__ cell_start, int tile,
-                                              int tiles_per_col, int tile_cells, int col0, TileGeom& g) {
-    g.col = col0 + tile / tiles_per_col;
-    int trow = tile % tiles_per_col;
+__device__ __forceinline__ void tile_geometry(const DevConsts& c, const int* __restrict__ cell_start, int col,
+                                              int trow, int tile_cells, TileGeom& g) {
+    g.col = col;
     g.cy0 = trow * tile_cells;
     g.cy1 = min(g.cy0 + tile_cells, c.ny);
     g.ylo = max(g.cy0 - 1, 0);
@@ -77,14 +76,15 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_density(DevConsts c, const flo
                                                            const uint32_t* __restrict__ skeys,
                                                            const int* __restrict__ cell_start,
                                                            float* __restrict__ rho, float* __restrict__ prs,
-                                                           int* __restrict__ ncount, int col0, int tiles_per_col,
-                                                           int tile_cells, int ntiles, int cap) {
+                                                           int* __restrict__ ncount, int col0, int ncols,
+                                                           int tiles_per_col, int tile_cells, int cap) {
     extern __shared__ __align__(16) float4 s_dyn[];
     float2* s_pos = reinterpret_cast<float2*>(s_dyn);
     int* s_cs = reinterpret_cast<int*>(s_pos + cap);
-    int tile = sph_xcd_remap(blockIdx.x, ntiles);
+    int tcol, trow;
+    if (!sph_tile_of_block(blockIdx.x, ncols, tiles_per_col, tcol, trow)) return;
     TileGeom g;
-    tile_geometry(c, cell_start, tile, tiles_per_col, tile_cells, col0, g);
+    tile_geometry(c, cell_start, col0 + tcol, trow, tile_cells, g);
     if (g.own_lo == g.own_hi) return;  // uniform: empty tile
     const bool use_lds = g.total <= cap;
     if (use_lds) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_force(DevConsts c, const float
                                                          const uint32_t* __restrict__ skeys,
                                                          const int* __restrict__ cell_start,
                                                          float2* __restrict__ pos_o, float2* __restrict__ vel_o,
-                                                         int col0, int tiles_per_col, int tile_cells, int ntiles,
+                                                         int col0, int ncols, int tiles_per_col, int tile_cells,
                                                          int cap, int own_lo_col, int own_hi_col, float mx, float my,
                                                          float strength) {
     extern __shared__ __align__(16) float4 s_dyn[];  // [cap] float4 aux, [cap] float2 pos, cell starts
@@ -252,9 +252,10 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_force(DevConsts c, const float
     float2* s_pos = reinterpret_cast<float2*>(s_dyn + cap);
     int* s_cs = reinterpret_cast<int*>(s_pos + cap);
 
-    int tile = sph_xcd_remap(blockIdx.x, ntiles);
+    int tcol, trow;
+    if (!sph_tile_of_block(blockIdx.x, ncols, tiles_per_col, tcol, trow)) return;
     TileGeom g;
-    tile_geometry(c, cell_start, tile, tiles_per_col, tile_cells, col0, g);
+    tile_geometry(c, cell_start, col0 + tcol, trow, tile_cells, g);
     if (g.own_lo == g.own_hi) return;
     if (g.col < own_lo_col || g.col >= own_hi_col) {  // ghost column: pass through
         for (int s = g.own_lo + (int)threadIdx.x; s < g.own_hi; s += PAIR_THREADS) {
@@ -351,9 +352,8 @@ __global__ __launch_bounds__(256) void k_integrate(DevConsts c, float2* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-static void tile_launch_dims(const SphCtx* c, int col_lo, int col_hi, int& tiles_per_col, int& ntiles) {
-    tiles_per_col = (c->dc.ny + c->tile_cells - 1) / c->tile_cells;
-    ntiles = tiles_per_col * (col_hi - col_lo);
+static TileMap tile_launch_dims(const SphCtx* c, int col_lo, int col_hi) {
+    return sph_tile_map(col_hi - col_lo, (c->dc.ny + c->tile_cells - 1) / c->tile_cells);
 }
 
 int sph_density_launch(SphCtx* c) {
@@ -362,11 +362,11 @@ int sph_density_launch(SphCtx* c) {
     // one column wider than the owned range: ghost densities are recomputed locally
     int lo = c->col_lo > 0 ? c->col_lo - 1 : 0;
     int hi = c->col_hi < c->dc.nx ? c->col_hi + 1 : c->dc.nx;
-    int tpc, ntiles;
-    tile_launch_dims(c, lo, hi, tpc, ntiles);
+    TileMap tm = tile_launch_dims(c, lo, hi);
     size_t lds = sizeof(float2) * (size_t)c->pair_cap + sizeof(int) * 3 * CS_STRIDE;
-    hipLaunchKernelGGL(k_density, dim3(ntiles), dim3(PAIR_THREADS), lds, c->stream, c->dc, c->pos, c->keys,
-                       c->cell_start, c->rho, c->prs, c->ncount, lo, tpc, c->tile_cells, ntiles, c->pair_cap);
+    hipLaunchKernelGGL(k_density, dim3(tm.nblocks), dim3(PAIR_THREADS), lds, c->stream, c->dc, c->pos, c->keys,
+                       c->cell_start, c->rho, c->prs, c->ncount, lo, tm.ncols, tm.tiles_per_col, c->tile_cells,
+                       c->pair_cap);
     LAUNCH_CHECK();
     c->counts_valid = true;
     return SPHHIP_OK;
@@ -375,21 +375,20 @@ int sph_density_launch(SphCtx* c) {
 int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate) {
     if (c->n == 0) return SPHHIP_OK;
     PhaseScope ps(c, SPHHIP_PH_FORCE);
-    int tpc, ntiles;
-    tile_launch_dims(c, 0, c->dc.nx, tpc, ntiles);  // all columns: ghost tiles pass through
+    TileMap tm = tile_launch_dims(c, 0, c->dc.nx);  // all columns: ghost tiles pass through
     size_t lds = (sizeof(float4) + sizeof(float2)) * (size_t)c->pair_cap + sizeof(int) * 3 * CS_STRIDE;
     if (fuse_integrate) {
-        hipLaunchKernelGGL(k_force<true>, dim3(ntiles), dim3(PAIR_THREADS), lds, c->stream, c->dc, c->pos, c->vel,
-                           c->rho, c->prs, c->idv, c->keys, c->cell_start, c->pos2, c->vel2, 0, tpc, c->tile_cells,
-                           ntiles, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength);
+        hipLaunchKernelGGL(k_force<true>, dim3(tm.nblocks), dim3(PAIR_THREADS), lds, c->stream, c->dc, c->pos, c->vel,
+                           c->rho, c->prs, c->idv, c->keys, c->cell_start, c->pos2, c->vel2, 0, tm.ncols,
+                           tm.tiles_per_col, c->tile_cells, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength);
         LAUNCH_CHECK();
         std::swap(c->pos, c->pos2);
         std::swap(c->vel, c->vel2);
         c->grid_valid = false;
     } else {
-        hipLaunchKernelGGL(k_force<false>, dim3(ntiles), dim3(PAIR_THREADS), lds, c->stream, c->dc, c->pos, c->vel,
-                           c->rho, c->prs, c->idv, c->keys, c->cell_start, c->pos2, c->vel2, 0, tpc, c->tile_cells,
-                           ntiles, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength);
+        hipLaunchKernelGGL(k_force<false>, dim3(tm.nblocks), dim3(PAIR_THREADS), lds, c->stream, c->dc, c->pos, c->vel,
+                           c->rho, c->prs, c->idv, c->keys, c->cell_start, c->pos2, c->vel2, 0, tm.ncols,
+                           tm.tiles_per_col, c->tile_cells, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength);
         LAUNCH_CHECK();
         std::swap(c->vel, c->vel2);
     }

@@ -131,11 +131,36 @@ __device__ __forceinline__ int sph_cell_coord(float x, float x0, float inv_cell,
     return c;
 }
 
-// XCD-aware workgroup remap (bijective for any grid size): workgroups b and b+8 share an XCD
-// under round-robin dispatch, so give each XCD a contiguous run of logical tiles -- neighbouring
-// tiles (which share neighbour-column data) then hit the same L2.  Speed only, never correctness.
-__device__ __forceinline__ int sph_xcd_remap(int b, int nb) {
-    int xcd = b & 7, q = nb >> 3, r = nb & 7;
-    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (b >> 3);
+// XCD-aware workgroup -> tile map for the pair kernels.  Workgroups b and b+8 share an XCD (and its
+// L2) under round-robin dispatch.  Grid columns are cut into bands of PAIR_BAND_COLS adjacent
+// columns; band j belongs to XCD j % 8, and an XCD walks its bands row by row, so the workgroups an
+// XCD runs together are horizontally adjacent tiles -- they share two of their three candidate
+// columns through that XCD's L2.  Bands (not one contiguous chunk per XCD) keep all eight XCDs busy
+// when the fluid occupies only part of the domain (dam break).  Speed only, never correctness:
+// the map is a bijection onto a superset of the tiles; out-of-range workgroups exit.
+constexpr int PAIR_BAND_COLS = 4;
+
+struct TileMap {
+    int ncols, tiles_per_col, nblocks;
+};
+
+static inline TileMap sph_tile_map(int ncols, int tiles_per_col) {
+    TileMap m;
+    m.ncols = ncols;
+    m.tiles_per_col = tiles_per_col;
+    int nbands = (ncols + PAIR_BAND_COLS - 1) / PAIR_BAND_COLS;
+    int bands_per_xcd = (nbands + 7) / 8;
+    m.nblocks = 8 * bands_per_xcd * PAIR_BAND_COLS * tiles_per_col;
+    return m;
+}
+
+// -> false if this workgroup has no tile
+__device__ __forceinline__ bool sph_tile_of_block(int b, int ncols, int tiles_per_col, int& col, int& trow) {
+    int xcd = b & 7, q = b >> 3;
+    int per_band = PAIR_BAND_COLS * tiles_per_col;
+    int band = xcd + 8 * (q / per_band);
+    int r = q % per_band;
+    col = band * PAIR_BAND_COLS + (r % PAIR_BAND_COLS);
+    trow = r / PAIR_BAND_COLS;
+    return col < ncols;
 }
