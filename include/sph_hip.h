@@ -1,0 +1,59 @@
+// sph_hip.h -- C++ host-side drop-in: the reference's step interface (SPH/sph.h:35-39) and
+// dispatcher entry points (SPH/main.h:52-59) for the MI355X path, implemented over the C ABI of
+// include/sphhip.h (libsphhip.so) by sph_amd/csrc/host_shim.cpp.
+//
+// Same shapes, argument meaning and ownership as the reference's functions: free functions on the
+// caller-owned `std::vector<Particle>&`, all `void`, index i stable.  Include the reference's
+// "sph.h" BEFORE this header when building inside the reference tree; standalone builds get
+// layout-compatible `float2` / `Particle` definitions from here.
+#pragma once
+#ifndef SPH_H  // standalone: interface types of SPH/sph.h:22-33 (layout fixed by the reference)
+#include <vector>
+struct float2 {
+    float x, y;
+    float2(float x_ = 0.0f, float y_ = 0.0f) : x(x_), y(y_) {}
+};
+struct Particle {
+    float2 pos;
+    float2 vel;
+    float density;
+    float pressure;
+    bool valid;
+};
+#endif
+static_assert(sizeof(Particle) == 28, "Particle must keep the reference's 28-byte layout (SPH/sph.h:27-33)");
+
+// serial_initSimulation (SPH/sph.cpp:132-164) / initSimulation (SPH/sph.cu:166-205): lattice fill of
+// [0.05,1.95]^2; resizes the vector.  Host arithmetic, identical bits.
+void hip_initSimulation(std::vector<Particle>& particles, int N);
+// Neighbour search (no reference counterpart beyond the dead grid/cellStart/cellEnd parameters,
+// SPH/sph.cuh:33-34,38).  Outputs are optional (nullptr): cell key per sorted slot, particle index
+// per sorted slot, half-open slot range of each of the nx*ny cells.
+void hip_buildNeighbors(std::vector<Particle>& particles, int N, std::vector<int>* keys, std::vector<int>* order,
+                        std::vector<int>* cellStart, std::vector<int>* cellEnd);
+// serial_computeDensityPressure (SPH/sph.cpp:41-55)
+void hip_computeDensityPressure(std::vector<Particle>& particles, int N);
+// serial_computeForces (SPH/sph.cpp:57-99), snapshot neighbour velocities (SPH/MPI_sph.cpp:144-147)
+void hip_computeForces(std::vector<Particle>& particles, int N, float2 mousePos, float interactionStrength);
+// serial_integrate (SPH/sph.cpp:101-130)
+void hip_integrate(std::vector<Particle>& particles, int N);
+// serial_stepSimulation (SPH/sph.cpp:166-171); like stepSimulation of the CUDA flavour it refreshes
+// the caller's host array on every call (SPH/sph.cu:235).
+void hip_stepSimulation(std::vector<Particle>& particles, int N, float2 mousePos, float interactionStrength);
+// nsteps steps with the state resident in HBM, one upload and one download.
+void hip_stepSimulationResident(std::vector<Particle>& particles, int N, float2 mousePos, float interactionStrength,
+                                int nsteps);
+// cleanupSimulation (SPH/sph.cu:275-280): releases the cached device context.
+void hip_cleanupSimulation();
+
+// Dispatcher family of SPH/main.h:52-59.  HIP_main is headless (rendering stays off the timed
+// path): runs `steps` steps of the default scene and optionally dumps the final state (28-byte
+// records) to `dump_path`.  HIP_performance_test follows serial_performance_test
+// (SPH/serial_main.cpp:120-147): lattice init, 10 runs x 100 steps, mean of 100/elapsed (UPS);
+// the per-step prints of the reference are kept out of the timed region.
+int HIP_main(int N);
+int HIP_main_headless(int N, int steps, const char* dump_path);
+float HIP_performance_test(int N);
+// Last error text of the shim ("" if none); the reference's functions have no error channel, so
+// failures are reported here and on stderr, never by exit() (contrast SPH/sph.cuh:17-23).
+const char* hip_lastError();

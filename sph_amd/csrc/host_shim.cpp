@@ -1,0 +1,192 @@
+// host_shim.cpp -- C++ host side above the C ABI: the reference's step interface and dispatcher
+// entry points for the MI355X path (see include/sph_hip.h).  Plain C++ (no HIP headers: the
+// reference's global `float2` collides with HIP's); links against libsphhip.so.
+#include "../../include/sph_hip.h"
+#include "../../include/sphhip.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <string>
+
+namespace {
+SphCtx* g_ctx = nullptr;
+int g_cap = 0;
+std::string g_err;
+
+bool fail(const char* where, int rc) {
+    g_err = std::string(where) + ": " + sphhip_last_error() + " (code " + std::to_string(rc) + ")";
+    std::fprintf(stderr, "[sph_hip] %s\n", g_err.c_str());
+    return false;
+}
+
+// One cached context per process (the reference's CUDA flavour keeps a hidden global device buffer,
+// SPH/sph.cu:10); re-created when a larger N arrives.
+bool ensure_ctx(int n) {
+    if (g_ctx && n <= g_cap) return true;
+    if (g_ctx) {
+        sphhip_destroy(g_ctx);
+        g_ctx = nullptr;
+    }
+    SphParams p;
+    sphhip_default_params(&p);
+    int cap = n > 1024 ? n : 1024;
+    int rc = sphhip_create(&p, cap, 0, &g_ctx);
+    if (rc) return fail("sphhip_create", rc);
+    g_cap = cap;
+    return true;
+}
+
+bool upload(std::vector<Particle>& v, int n) {
+    if ((int)v.size() < n) {
+        g_err = "particle vector smaller than N";
+        return false;
+    }
+    if (!ensure_ctx(n)) return false;
+    int rc = sphhip_upload(g_ctx, v.data(), n, 0);
+    return rc ? fail("sphhip_upload", rc) : true;
+}
+
+bool download(std::vector<Particle>& v, int n) {
+    int rc = sphhip_download(g_ctx, v.data(), n);
+    return rc ? fail("sphhip_download", rc) : true;
+}
+}  // namespace
+
+const char* hip_lastError() { return g_err.c_str(); }
+
+void hip_cleanupSimulation() {
+    if (g_ctx) sphhip_destroy(g_ctx);
+    g_ctx = nullptr;
+    g_cap = 0;
+}
+
+void hip_initSimulation(std::vector<Particle>& particles, int N) {
+    particles.resize(N);
+    // SPH/sph.cpp:136-152, same expression order in binary32
+    int cols = static_cast<int>(std::ceil(std::sqrt((double)N)));
+    int rows = cols > 0 ? (N + cols - 1) / cols : 0;
+    if (rows == 0) rows = 1;
+    const float minPos = 0.05f, maxPos = 1.95f;
+    const float range = maxPos - minPos;
+    float spacingX = range / (cols > 1 ? cols - 1 : 1);
+    float spacingY = range / (rows > 1 ? rows - 1 : 1);
+    float spacing = spacingY < spacingX ? spacingY : spacingX;
+    float startX = minPos + (range - (cols - 1) * spacing) / 2.0f;
+    float startY = maxPos - (range - (rows - 1) * spacing) / 2.0f;
+    for (int i = 0; i < N; i++) {
+        std::memset((void*)&particles[i], 0, sizeof(Particle));
+        particles[i].pos = float2(startX + (i % cols) * spacing, startY - (i / cols) * spacing);
+        particles[i].vel = float2(0.0f, 0.0f);
+        particles[i].density = 1000.0f;  // REST_DENSITY
+        particles[i].pressure = 0.0f;
+        particles[i].valid = true;
+    }
+}
+
+void hip_buildNeighbors(std::vector<Particle>& particles, int N, std::vector<int>* keys, std::vector<int>* order,
+                        std::vector<int>* cellStart, std::vector<int>* cellEnd) {
+    if (!upload(particles, N)) return;
+    int rc = sphhip_build_grid(g_ctx);
+    if (rc) {
+        fail("sphhip_build_grid", rc);
+        return;
+    }
+    SphParams p;
+    SphDerived d;
+    sphhip_default_params(&p);
+    sphhip_derive(&p, &d);
+    if (keys) keys->resize(N);
+    if (order) order->resize(N);
+    if (cellStart) cellStart->resize((size_t)d.nx * d.ny);
+    if (cellEnd) cellEnd->resize((size_t)d.nx * d.ny);
+    rc = sphhip_get_cells(g_ctx, keys ? keys->data() : nullptr, order ? order->data() : nullptr,
+                          cellStart ? cellStart->data() : nullptr, cellEnd ? cellEnd->data() : nullptr);
+    if (rc) fail("sphhip_get_cells", rc);
+}
+
+void hip_computeDensityPressure(std::vector<Particle>& particles, int N) {
+    if (!upload(particles, N)) return;
+    int rc = sphhip_density(g_ctx);
+    if (rc) {
+        fail("sphhip_density", rc);
+        return;
+    }
+    download(particles, N);
+}
+
+void hip_computeForces(std::vector<Particle>& particles, int N, float2 mousePos, float interactionStrength) {
+    if (!upload(particles, N)) return;
+    int rc = sphhip_forces(g_ctx, mousePos.x, mousePos.y, interactionStrength);
+    if (rc) {
+        fail("sphhip_forces", rc);
+        return;
+    }
+    download(particles, N);
+}
+
+void hip_integrate(std::vector<Particle>& particles, int N) {
+    if (!upload(particles, N)) return;
+    int rc = sphhip_integrate(g_ctx);
+    if (rc) {
+        fail("sphhip_integrate", rc);
+        return;
+    }
+    download(particles, N);
+}
+
+void hip_stepSimulationResident(std::vector<Particle>& particles, int N, float2 mousePos, float interactionStrength,
+                                int nsteps) {
+    if (!upload(particles, N)) return;
+    int rc = sphhip_step(g_ctx, mousePos.x, mousePos.y, interactionStrength, nsteps);
+    if (rc) {
+        fail("sphhip_step", rc);
+        return;
+    }
+    download(particles, N);
+}
+
+void hip_stepSimulation(std::vector<Particle>& particles, int N, float2 mousePos, float interactionStrength) {
+    hip_stepSimulationResident(particles, N, mousePos, interactionStrength, 1);
+}
+
+float HIP_performance_test(int N) {
+    std::vector<Particle> particles;
+    hip_initSimulation(particles, N);
+    if (!upload(particles, N)) return 0.0f;
+    const int num_steps = 100, num_runs = 10;  // SPH/serial_main.cpp:124-125
+    double total_ups = 0.0;
+    for (int run = 0; run < num_runs; ++run) {
+        std::cout << "Run: " << run + 1 << " / " << num_runs << std::endl;  // outside the timed region
+        if (sphhip_synchronize(g_ctx)) return 0.0f;
+        auto t0 = std::chrono::high_resolution_clock::now();
+        int rc = sphhip_step(g_ctx, 0.0f, 0.0f, 0.0f, num_steps);  // mouse off, serial_main.cpp:129-130
+        if (!rc) rc = sphhip_synchronize(g_ctx);
+        auto t1 = std::chrono::high_resolution_clock::now();
+        if (rc) {
+            fail("sphhip_step", rc);
+            return 0.0f;
+        }
+        std::chrono::duration<double> elapsed = t1 - t0;
+        total_ups += num_steps / elapsed.count();
+    }
+    return (float)(total_ups / num_runs);
+}
+
+int HIP_main_headless(int N, int steps, const char* dump_path) {
+    std::vector<Particle> particles;
+    hip_initSimulation(particles, N);
+    hip_stepSimulationResident(particles, N, float2(0.0f, 0.0f), 0.0f, steps);
+    if (!g_err.empty()) return -1;
+    if (dump_path && *dump_path) {
+        FILE* f = std::fopen(dump_path, "wb");
+        if (!f) return -1;
+        std::fwrite(particles.data(), sizeof(Particle), (size_t)N, f);
+        std::fclose(f);
+    }
+    return 0;
+}
+
+int HIP_main(int N) { return HIP_main_headless(N, 1000, nullptr); }
