@@ -130,18 +130,18 @@ def main():
     else:
         import torch.distributed as dist
 
-        from sph_amd.slab import SlabSolver
+        from sph_amd import lib as _lib
+        from sph_amd.slab import make_hip_slab
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         # weak scaling: the fluid column gets `world` times wider, per-GPU particle count fixed
-        params, n_total, make_local = scenes.dam_break_sharded(cols * world, rows)
-        solver = SlabSolver(params, n_total, make_local, device=local_rank)
+        params, n_total, hist_fn, make_local = scenes.dam_break_sharded(cols * world, rows)
+        drv = _lib.derive(params)
+        solver = make_hip_slab(params, make_local, local_rank, hist=hist_fn(drv))
         step = lambda k: solver.step(nsteps=k)  # noqa: E731
         sync = lambda: torch.cuda.synchronize()  # noqa: E731
         barrier = lambda: dist.barrier()  # noqa: E731
         parallelism = "x-slabs x%d, 2-column ghost halo + migration over RCCL" % world
-        drv = solver.solver.drv
-        solver = solver.solver if False else solver
 
     step(args.warmup)
     sync()
@@ -159,6 +159,10 @@ def main():
     phases = inner.phase_times()
     inner.set_profiling(False)
     n_local = inner.n
+    if world > 1:
+        # particles this rank integrates per step (ghosts excluded): what the force kernel's
+        # algorithmic bytes are counted on
+        n_local = n_total // world
 
     if world > 1:
         import torch.distributed as dist
@@ -168,6 +172,9 @@ def main():
         elapsed = float(t.item())
 
     # neighbour statistics, off the timed path
+    if world > 1:
+        inner.drop_ghosts()
+        inner.set_owned_columns(0, drv.nx)  # count over this rank's own particles only (edge pairs are missed)
     inner.computeDensityPressure()
     pairs_local = inner.pair_count()
     if world > 1:

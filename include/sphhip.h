@@ -27,6 +27,7 @@ extern "C" {
 #endif
 
 #define SPHHIP_PARTICLE_BYTES 28
+#define SPHHIP_HALO_COLS 2 /* ghost columns a slab needs on each side (see sphhip_pack_halo) */
 
 enum {
     SPHHIP_OK = 0,
@@ -167,14 +168,20 @@ int sphhip_set_owned_columns(SphCtx* ctx, int col_lo, int col_hi);
 /* Classifies every particle by the grid column of its CURRENT position.  Copies it, as a 20-byte
  * record {x,y,vx,vy,idv}, into d_left if column < send_hi_left and into d_right if column >=
  * send_lo_right (device buffers, capacity in records; migrants and ghosts for the neighbour
- * slabs), and keeps it only if its column is inside the owned range set by
- * sphhip_set_owned_columns (this drops last step's ghosts and the particles that migrated
- * away).  Returns the two counts after a stream sync.  The grid is not required. */
+ * slabs).  Ghost copies left from the last step are dropped; a particle that has just left the
+ * owned columns (set by sphhip_set_owned_columns) is sent AND kept for one more step as a ghost
+ * while it is within SPHHIP_HALO_COLS columns of the slab, because it is still a neighbour of
+ * the particles that stay; anything farther out is dropped.  Returns the two counts after a
+ * stream sync.  The grid is not required. */
 int sphhip_pack_halo(SphCtx* ctx, int send_hi_left, int send_lo_right,
                      void* d_left, int cap_left, int* n_left,
                      void* d_right, int cap_right, int* n_right);
 /* Drops every particle whose column is outside [col_lo, col_hi); sends nothing. */
 int sphhip_keep_columns(SphCtx* ctx, int col_lo, int col_hi);
+/* Drops the ghost copies left over from the last step on a slab (particles that were outside the
+ * owned columns when that step sorted them); sphhip_pack_halo does the same implicitly.  Needed
+ * before a download that must return owned particles only. */
+int sphhip_drop_ghosts(SphCtx* ctx);
 /* Appends n 20-byte records (device memory) to the state; density/pressure of the new
  * particles are undefined until the next density pass. */
 int sphhip_append(SphCtx* ctx, const void* d_records, int n);

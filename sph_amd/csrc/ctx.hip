@@ -309,6 +309,7 @@ extern "C" int sphhip_upload(SphCtx* c, const void* aos28, int n, int id_base) {
     c->have_state = true;
     c->grid_valid = false;
     c->counts_valid = false;
+    c->slice_valid = false;
     return SPHHIP_OK;
 }
 
@@ -456,10 +457,15 @@ extern "C" int sphhip_get_pair_count(SphCtx* c, long long* pairs) {
     if (!pairs) return fail(SPHHIP_EINVAL, "null argument");
     if (!c->counts_valid) return fail(SPHHIP_ESTATE, "sphhip_get_pair_count: no density pass yet");
     std::vector<int> cnt(c->n);
+    int lo = 0, hi = c->n;
     if (c->n) HIP_TRY(hipMemcpyAsync(cnt.data(), c->ncount, sizeof(int) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    if (c->slice_valid) {  // on a slab: owned particles only (ghost pairs belong to the neighbour rank)
+        HIP_TRY(hipMemcpyAsync(&lo, c->cell_start + (size_t)c->slice_lo * c->dc.ny, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&hi, c->cell_start + (size_t)c->slice_hi * c->dc.ny, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     long long t = 0;
-    for (int v : cnt) t += (v > 0 ? v - 1 : 0);  // self excluded
+    for (int i = lo; i < hi; i++) t += (cnt[i] > 0 ? cnt[i] - 1 : 0);  // self excluded
     *pairs = t;
     return SPHHIP_OK;
 }
@@ -491,9 +497,15 @@ __global__ __launch_bounds__(256) void k_split(DevConsts c, int n, const float2*
                                                 HaloRec* __restrict__ right, int cap_right,
                                                 float2* __restrict__ pos_o, float2* __restrict__ vel_o,
                                                 float* __restrict__ rho_o, float* __restrict__ prs_o,
-                                                uint32_t* __restrict__ idv_o, int* __restrict__ counters) {
+                                                uint32_t* __restrict__ idv_o, int* __restrict__ counters,
+                                                const int* __restrict__ cell_start, int slice_lo_cell,
+                                                int slice_hi_cell) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // After a step on a slab the state still holds the ghost copies (unmoved).  Slots are still in
+    // the order of that step's sort, so the particles this rank integrated are exactly the slot
+    // range of its owned columns; everything else is a stale ghost and is dropped here.
+    if (cell_start && (i < cell_start[slice_lo_cell] || i >= cell_start[slice_hi_cell])) return;
     float2 p = pos[i], v = vel[i];
     uint32_t w = idv[i];
     int col = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
@@ -516,18 +528,18 @@ __global__ __launch_bounds__(256) void k_split(DevConsts c, int n, const float2*
     }
 }
 
-extern "C" int sphhip_pack_halo(SphCtx* c, int send_hi_left, int send_lo_right, void* d_left, int cap_left,
-                                int* n_left, void* d_right, int cap_right, int* n_right) {
-    NEED_STATE(c);
+static int split_impl(SphCtx* c, int send_hi_left, int send_lo_right, int keep_lo, int keep_hi, void* d_left,
+                      int cap_left, int* n_left, void* d_right, int cap_right, int* n_right) {
     if (!n_left || !n_right) return fail(SPHHIP_EINVAL, "null argument");
     if ((cap_left > 0 && !d_left) || (cap_right > 0 && !d_right)) return fail(SPHHIP_EINVAL, "null buffer");
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(int) * 4, c->stream));
     const int n = c->n;
     if (n > 0) {
         hipLaunchKernelGGL(k_split, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dc, n, c->pos, c->vel, c->rho,
-                           c->prs, c->idv, send_hi_left, send_lo_right, c->col_lo, c->col_hi, (HaloRec*)d_left,
+                           c->prs, c->idv, send_hi_left, send_lo_right, keep_lo, keep_hi, (HaloRec*)d_left,
                            cap_left, (HaloRec*)d_right, cap_right, c->pos2, c->vel2, c->rho2, c->prs2, c->idv2,
-                           c->counters);
+                           c->counters, c->slice_valid ? c->cell_start : nullptr, c->slice_lo * c->dc.ny,
+                           c->slice_hi * c->dc.ny);
         LAUNCH_CHECK();
     }
     int h[4] = {0, 0, 0, 0};
@@ -546,19 +558,31 @@ extern "C" int sphhip_pack_halo(SphCtx* c, int send_hi_left, int send_lo_right, 
     c->n = h[2];
     c->grid_valid = false;
     c->counts_valid = false;
+    c->slice_valid = false;
     return SPHHIP_OK;
+}
+
+extern "C" int sphhip_pack_halo(SphCtx* c, int send_hi_left, int send_lo_right, void* d_left, int cap_left,
+                                int* n_left, void* d_right, int cap_right, int* n_right) {
+    NEED_STATE(c);
+    // A particle that has just left the owned columns is handed to the neighbour in this very call,
+    // but it is still a neighbour of the particles that stay: keep it (as a ghost, one more step)
+    // while it lies inside the halo.  The next call drops it through the owned-slot slice.
+    return split_impl(c, send_hi_left, send_lo_right, c->col_lo - SPHHIP_HALO_COLS, c->col_hi + SPHHIP_HALO_COLS,
+                      d_left, cap_left, n_left, d_right, cap_right, n_right);
 }
 
 extern "C" int sphhip_keep_columns(SphCtx* c, int lo, int hi) {
     NEED_STATE(c);
-    int save_lo = c->col_lo, save_hi = c->col_hi;
-    c->col_lo = lo;
-    c->col_hi = hi;
     int nl, nr;
-    int rc = sphhip_pack_halo(c, -1, 0x7fffffff, nullptr, 0, &nl, nullptr, 0, &nr);
-    c->col_lo = save_lo;
-    c->col_hi = save_hi;
-    return rc;
+    return split_impl(c, -1, 0x7fffffff, lo, hi, nullptr, 0, &nl, nullptr, 0, &nr);
+}
+
+extern "C" int sphhip_drop_ghosts(SphCtx* c) {
+    NEED_STATE(c);
+    if (!c->slice_valid) return SPHHIP_OK;  // nothing was stepped with ghosts
+    int nl, nr;
+    return split_impl(c, -1, 0x7fffffff, 0, c->dc.nx, nullptr, 0, &nl, nullptr, 0, &nr);
 }
 
 __global__ __launch_bounds__(256) void k_append(const HaloRec* __restrict__ rec, int n, int at,
@@ -578,8 +602,12 @@ __global__ __launch_bounds__(256) void k_append(const HaloRec* __restrict__ rec,
 extern "C" int sphhip_append(SphCtx* c, const void* d_records, int n) {
     if (!c) return fail(SPHHIP_EINVAL, "null context");
     if (n < 0 || (n > 0 && !d_records)) return fail(SPHHIP_EINVAL, "sphhip_append: bad argument");
-    if (c->n + n > c->n_max) return fail(SPHHIP_ECAPACITY, "sphhip_append: exceeds the context capacity");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->slice_valid && c->have_state) {  // stale ghosts of the last step must not mix with new records
+        int rc = sphhip_drop_ghosts(c);
+        if (rc) return rc;
+    }
+    if (c->n + n > c->n_max) return fail(SPHHIP_ECAPACITY, "sphhip_append: exceeds the context capacity");
     if (n > 0) {
         hipLaunchKernelGGL(k_append, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const HaloRec*)d_records, n,
                            c->n, c->pos, c->vel, c->rho, c->prs, c->idv, c->params.rest_density);

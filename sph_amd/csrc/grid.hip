@@ -400,5 +400,9 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     }
     c->grid_valid = true;
     c->counts_valid = false;
+    // when only part of the columns is owned, remember which slot range that is (ghost dropping)
+    c->slice_valid = (c->col_lo > 0 || c->col_hi < c->dc.nx);
+    c->slice_lo = c->col_lo;
+    c->slice_hi = c->col_hi;
     return SPHHIP_OK;
 }

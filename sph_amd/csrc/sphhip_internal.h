@@ -53,6 +53,8 @@ struct SphCtx {
     bool have_state = false;
     bool grid_valid = false;
     bool counts_valid = false;
+    bool slice_valid = false;    // slots of [slice_lo, slice_hi) columns (at the last sort) = owned particles
+    int slice_lo = 0, slice_hi = 0;
     int col_lo = 0, col_hi = 0;  // owned columns (default: all)
     int tile_cells = 16;         // cells of a column per pair-kernel workgroup
     int pair_cap = 1536;         // neighbour candidates staged in LDS per workgroup

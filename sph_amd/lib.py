@@ -40,6 +40,7 @@ SIGNATURES = {
     "sphhip_set_owned_columns": [_vp, _ci, _ci],
     "sphhip_pack_halo": [_vp, _ci, _ci, _vp, _ci, _pi, _vp, _ci, _pi],
     "sphhip_keep_columns": [_vp, _ci, _ci],
+    "sphhip_drop_ghosts": [_vp],
     "sphhip_append": [_vp, _vp, _ci],
     "sphhip_column_histogram": [_vp, _vp],
     "sphhip_set_profiling": [_vp, _ci],

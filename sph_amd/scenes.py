@@ -84,3 +84,38 @@ def uniform_box(side, spacing=None, base=None):
     p = _params_for_box(width, width, base)
     a = _block(side, side, sp, p.xmin, p.ymin, base.rest_density)
     return p, a
+
+
+def dam_break_sharded(cols, rows=None, spacing=None, base=None):
+    """The dam-break scene for slab-decomposed runs: returns (params, n_total, column_hist_fn,
+    make_local) where make_local(c0, c1, drv) generates only the particles whose grid column is in
+    [c0, c1) together with their global ids (id = row * cols + col, as `dam_break` numbers them)."""
+    rows = rows or cols
+    base = base or SphParams.reference()
+    sp = F(spacing) if spacing else F(base.h / F(4.0))
+    w = F(F(cols) * sp)
+    p = _params_for_box(F(4.0) * w, F(2.0) * w, base)
+    xs = (F(p.xmin) + np.arange(cols).astype(np.float32) * sp).astype(np.float32)
+    ys = (F(p.ymin) + np.arange(rows).astype(np.float32) * sp).astype(np.float32)
+
+    def lattice_cols(drv):
+        f = np.floor((xs - F(p.xmin)) * F(drv.inv_cell))
+        return np.clip(f, 0, drv.nx - 1).astype(np.int64)
+
+    def column_hist(drv):
+        return np.bincount(lattice_cols(drv), minlength=drv.nx) * rows
+
+    def make_local(c0, c1, drv):
+        gc = lattice_cols(drv)
+        mine = np.nonzero((gc >= c0) & (gc < c1))[0]
+        n = len(mine) * rows
+        a = np.zeros(n, PARTICLE_DTYPE)
+        cc, rr = np.meshgrid(mine, np.arange(rows))
+        a["pos"][:, 0] = xs[cc.ravel()]
+        a["pos"][:, 1] = ys[rr.ravel()]
+        a["density"] = F(base.rest_density)
+        a["valid"] = 1
+        ids = rr.ravel().astype(np.int64) * cols + cc.ravel()
+        return a, ids
+
+    return p, cols * rows, column_hist, make_local

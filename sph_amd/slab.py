@@ -1,0 +1,273 @@
+"""Multi-GPU driver: 1-D spatial slabs along x with ghost-column halo exchange and particle
+migration, one process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in
+the CPU tests).
+
+Replaces the reference's MPI partitioning (SPH/MPI_sph.cpp:135-166,255-257): there every rank
+holds ALL particles, owns an index block, and receives 24*N bytes per step through four
+MPI_Allgathers.  Here rank g owns the grid columns [bounds[g], bounds[g+1]) -- a contiguous key range
+because cell keys are column-major -- and per step exchanges, with its two x-neighbours only:
+  * the particles of its two outermost columns on each side (ghosts for the neighbour; two columns
+    so that the neighbour can recompute the density of its first ghost column locally, which
+    replaces the dens/pres Allgathers of MPI_sph.cpp:163-166), and
+  * the particles whose position left the slab (migrants; the neighbour becomes their owner),
+in ONE message per direction: 20-byte records {x, y, vx, vy, id|valid}.  No collective is on the
+per-step path; rebalancing uses one all-reduce of the per-column histogram (nx ints).
+
+Results are identical to the single-GPU path bit for bit: the sorted order is canonical
+(key, id) whatever order particles arrive in, ghosts are sorted into the same cells, and every
+owned particle sums the same neighbours in the same order.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import lib as _lib
+from .params import HALO_DTYPE
+from .solver import Solver
+
+HALO_COLS = 2  # SPHHIP_HALO_COLS
+# A slab must be wider than the halo: a particle that enters a neighbour's slab from its far side
+# must not land inside my ghost range in the same step (it would reach me one step late).
+MIN_SLAB_COLS = HALO_COLS + 1
+BIG = 0x7FFFFFFF
+
+
+def grid_column(x, params, drv):
+    """Grid column of x-coordinates, same binary32 arithmetic as the device (sph_cell_coord)."""
+    x = np.asarray(x, np.float32)
+    f = np.floor((x - np.float32(params.xmin)) * np.float32(drv.inv_cell))
+    return np.clip(np.nan_to_num(f, nan=0.0), 0, drv.nx - 1).astype(np.int64)
+
+
+def balanced_bounds(hist, world, min_width=MIN_SLAB_COLS, prev=None):
+    """Column boundaries giving every rank about the same particle count.  Every slab is at least
+    `min_width` columns wide (a halo never spans more than one neighbour).  With `prev`, boundary g
+    stays strictly between prev[g-1] and prev[g+1] so that every particle's new owner is its old
+    owner or an adjacent rank (migration is nearest-neighbour only)."""
+    hist = np.asarray(hist, np.int64)
+    nx = len(hist)
+    if nx < world * min_width:
+        raise ValueError("grid has %d columns: too few for %d slabs of >= %d columns" % (nx, world, min_width))
+    csum = np.concatenate([[0], np.cumsum(hist)])
+    total = csum[-1]
+    b = [0]
+    for g in range(1, world):
+        target = total * g / world
+        c = int(np.searchsorted(csum, target, side="left"))
+        lo = b[-1] + min_width
+        hi = nx - (world - g) * min_width
+        if prev is not None:
+            lo = max(lo, prev[g - 1] + min_width)
+            hi = min(hi, prev[g + 1] - min_width)
+        b.append(int(min(max(c, lo), hi)))
+    b.append(nx)
+    return b
+
+
+class HipSlabBackend:
+    """The product backend: libsphhip.so on one GPU, exchange buffers as torch CUDA tensors."""
+
+    def __init__(self, params, n_max, device, halo_cap):
+        self.device = torch.device("cuda", device)
+        self.solver = Solver(params, n_max=n_max, device=device)
+        self.drv = self.solver.drv
+        # run the library on torch's current stream so that RCCL ops and kernels are ordered
+        self.solver.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.halo_cap = int(halo_cap)
+        self.send_l = torch.empty((self.halo_cap, 5), dtype=torch.int32, device=self.device)
+        self.send_r = torch.empty((self.halo_cap, 5), dtype=torch.int32, device=self.device)
+
+    def new_buffer(self, n):
+        return torch.empty((n, 5), dtype=torch.int32, device=self.device)
+
+    def set_owned(self, lo, hi):
+        self.solver.set_owned_columns(lo, hi)
+
+    def pack(self, send_hi_left, send_lo_right):
+        nl, nr = self.solver.pack_halo(send_hi_left, send_lo_right, self.send_l.data_ptr(), self.halo_cap,
+                                       self.send_r.data_ptr(), self.halo_cap)
+        return self.send_l[:nl], self.send_r[:nr]
+
+    def append(self, rec):
+        if rec.shape[0]:
+            assert rec.is_contiguous()
+            self.solver.append(rec.data_ptr(), rec.shape[0])
+
+    def append_host(self, rec_np):
+        t = torch.from_numpy(np.ascontiguousarray(rec_np).view(np.int32).reshape(-1, 5)).to(self.device)
+        self.append(t)
+        torch.cuda.synchronize(self.device)
+
+    def step(self, mouse, strength):
+        self.solver.stepSimulation(mouse, strength, 1)
+
+    def drop_ghosts(self):
+        self.solver.drop_ghosts()
+
+    def download(self):
+        return self.solver.download(with_ids=True)
+
+    def column_histogram(self):
+        return self.solver.column_histogram()
+
+    @property
+    def n(self):
+        return self.solver.n
+
+
+class SlabSolver:
+    """x-slab decomposition of one scene over the ranks of a process group."""
+
+    def __init__(self, backend, params, bounds, group=None):
+        self.backend = backend
+        self.params = params
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.solver = getattr(backend, "solver", None)
+        # gloo cannot send CUDA tensors: stage the messages through host memory (tests / debugging);
+        # under nccl (RCCL) the device buffers go straight over xGMI
+        self.stage_cpu = dist.get_backend(group) == "gloo"
+        self.set_bounds(bounds)
+
+    # -- partition ----------------------------------------------------------------------------
+    def set_bounds(self, bounds):
+        bounds = [int(b) for b in bounds]
+        assert len(bounds) == self.world + 1 and bounds[0] == 0
+        for g in range(self.world):
+            assert bounds[g + 1] - bounds[g] >= MIN_SLAB_COLS, "slab not wider than the halo"
+        self.bounds = bounds
+        self.c0, self.c1 = bounds[self.rank], bounds[self.rank + 1]
+        self.backend.set_owned(self.c0, self.c1)
+
+    def rebalance(self):
+        """Count-balanced boundaries from the global per-column histogram (one small all-reduce)."""
+        self.backend.drop_ghosts()
+        h = torch.from_numpy(self.backend.column_histogram().astype(np.int64))
+        dev = getattr(self.backend, "device", torch.device("cpu"))
+        h = h.to(dev)
+        dist.all_reduce(h, group=self.group)
+        self.set_bounds(balanced_bounds(h.cpu().numpy(), self.world, prev=self.bounds))
+        return self.bounds
+
+    # -- halo exchange + migration ------------------------------------------------------------
+    def _exchange(self, left, right):
+        r, w = self.rank, self.world
+        out_dev = left.device
+        if self.stage_cpu and out_dev.type != "cpu":
+            left, right = left.cpu(), right.cpu()
+        dev = left.device
+        has_l, has_r = r > 0, r < w - 1
+        cnt_out_l = torch.tensor([left.shape[0]], dtype=torch.int64, device=dev)
+        cnt_out_r = torch.tensor([right.shape[0]], dtype=torch.int64, device=dev)
+        cnt_in_l = torch.zeros(1, dtype=torch.int64, device=dev)
+        cnt_in_r = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops = []
+        if has_l:
+            ops += [dist.P2POp(dist.isend, cnt_out_l, self._peer(r - 1), self.group),
+                    dist.P2POp(dist.irecv, cnt_in_l, self._peer(r - 1), self.group)]
+        if has_r:
+            ops += [dist.P2POp(dist.isend, cnt_out_r, self._peer(r + 1), self.group),
+                    dist.P2POp(dist.irecv, cnt_in_r, self._peer(r + 1), self.group)]
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        n_in_l, n_in_r = int(cnt_in_l.item()), int(cnt_in_r.item())
+        if dev == out_dev:
+            recv_l, recv_r = self.backend.new_buffer(n_in_l), self.backend.new_buffer(n_in_r)
+        else:
+            recv_l = torch.empty((n_in_l, 5), dtype=torch.int32)
+            recv_r = torch.empty((n_in_r, 5), dtype=torch.int32)
+        ops = []
+        if has_l and left.shape[0]:
+            ops.append(dist.P2POp(dist.isend, left, self._peer(r - 1), self.group))
+        if has_l and n_in_l:
+            ops.append(dist.P2POp(dist.irecv, recv_l, self._peer(r - 1), self.group))
+        if has_r and right.shape[0]:
+            ops.append(dist.P2POp(dist.isend, right, self._peer(r + 1), self.group))
+        if has_r and n_in_r:
+            ops.append(dist.P2POp(dist.irecv, recv_r, self._peer(r + 1), self.group))
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        if dev != out_dev:
+            recv_l, recv_r = recv_l.to(out_dev), recv_r.to(out_dev)
+        return recv_l, recv_r
+
+    def _peer(self, group_rank):
+        return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
+
+    def step(self, nsteps=1, mouse=(0.0, 0.0), strength=0.0):
+        for _ in range(nsteps):
+            send_hi_left = self.c0 + HALO_COLS if self.rank > 0 else -1
+            send_lo_right = self.c1 - HALO_COLS if self.rank < self.world - 1 else BIG
+            left, right = self.backend.pack(send_hi_left, send_lo_right)
+            recv_l, recv_r = self._exchange(left, right)
+            self.backend.append(recv_l)
+            self.backend.append(recv_r)
+            self.backend.step(mouse, strength)
+
+    # -- state --------------------------------------------------------------------------------
+    def download_local(self):
+        self.backend.drop_ghosts()
+        return self.backend.download()
+
+    def gather(self, n_total):
+        """All particles in id order on every rank (verification / dumps; off the timed path)."""
+        a, ids = self.download_local()
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (a, ids), group=self.group)
+        out = np.zeros(n_total, a.dtype)
+        seen = np.zeros(n_total, np.int32)
+        for pa, pid in parts:
+            out[pid] = pa
+            seen[pid] += 1
+        if not np.all(seen == 1):
+            raise RuntimeError("slab ownership broken: %d particles lost, %d duplicated" %
+                               (int((seen == 0).sum()), int((seen > 1).sum())))
+        return out
+
+    def local_count(self):
+        return self.backend.n
+
+
+def records_from_particles(a, ids):
+    """28-byte particles + global ids -> 20-byte halo records."""
+    r = np.zeros(len(a), HALO_DTYPE)
+    r["pos"] = a["pos"]
+    r["vel"] = a["vel"]
+    r["idv"] = np.asarray(ids, np.uint32) | np.where(a["valid"] != 0, 0, 0x80000000).astype(np.uint32)
+    return r
+
+
+def distribute(slab, particles, ids=None):
+    """Gives every rank the particles whose grid column it owns (each rank passes the same global
+    array, or its own disjoint share with explicit ids whose owners are then fixed up by the
+    normal migration of the first steps only if adjacent -- pass the full array when in doubt)."""
+    ids = np.arange(len(particles)) if ids is None else np.asarray(ids)
+    col = grid_column(particles["pos"][:, 0], slab.params, slab.backend.drv)
+    mine = (col >= slab.c0) & (col < slab.c1)
+    slab.backend.append_host(records_from_particles(particles[mine], ids[mine]))
+    return int(mine.sum())
+
+
+def make_hip_slab(params, particles_or_fn, device, group=None, hist=None):
+    """Builds the HIP-backed SlabSolver.  `particles_or_fn` is the global particle array, or a
+    function (c0, c1) -> (particles, ids) generating only the owned share (large scenes)."""
+    drv = _lib.derive(params)
+    world = dist.get_world_size(group)
+    if hist is None:
+        col = grid_column(particles_or_fn["pos"][:, 0], params, drv)
+        hist = np.bincount(col, minlength=drv.nx)
+    bounds = balanced_bounds(hist, world)
+    per = int(np.max([np.sum(hist[bounds[g]:bounds[g + 1]]) for g in range(world)]))
+    halo_cap = int(max(4 * HALO_COLS * np.max(hist), 4096))
+    n_max = int(per * 1.25) + 4 * halo_cap + 1024
+    backend = HipSlabBackend(params, n_max, device, halo_cap)
+    slab = SlabSolver(backend, params, bounds, group)
+    if callable(particles_or_fn):
+        a, ids = particles_or_fn(slab.c0, slab.c1, drv)
+        backend.append_host(records_from_particles(a, ids))
+    else:
+        distribute(slab, particles_or_fn)
+    return slab

@@ -139,6 +139,9 @@ class Solver:
     def keep_columns(self, lo, hi):
         _lib.check(self.L.sphhip_keep_columns(self.h, int(lo), int(hi)))
 
+    def drop_ghosts(self):
+        _lib.check(self.L.sphhip_drop_ghosts(self.h))
+
     def append(self, d_records, n):
         _lib.check(self.L.sphhip_append(self.h, ctypes.c_void_p(d_records), int(n)))
 

@@ -1,0 +1,116 @@
+"""The multi-rank slab path (sph_amd/slab.py) on CPU: world_size 2 and 3 under gloo, physics by the
+oracle-backed fake backend.  Checks that the slab-decomposed run equals the single-domain run bit
+for bit (same canonical summation order), that no particle is lost or duplicated while particles
+migrate across slab boundaries, and that rebalancing keeps ownership consistent."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import orc
+from sph_amd import lib as _lib
+from sph_amd import scenes
+from sph_amd.slab import SlabSolver, balanced_bounds, distribute, grid_column
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, scene, nsteps, rebalance_every, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_backend import FakeSlabBackend
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params, a = _scene(scene)
+        backend = FakeSlabBackend(params)
+        hist = np.bincount(grid_column(a["pos"][:, 0], params, backend.drv), minlength=backend.drv.nx)
+        slab = SlabSolver(backend, params, balanced_bounds(hist, world))
+        distribute(slab, a)
+        moved = 0
+        for s in range(nsteps):
+            if rebalance_every and s and s % rebalance_every == 0:
+                slab.rebalance()
+            before = backend.n
+            slab.step(1)
+            moved += abs(backend.n - before)
+        got = slab.gather(len(a))
+        if rank == 0:
+            np.save(out_path, got)
+    finally:
+        dist.destroy_process_group()
+
+
+def _scene(name):
+    if name == "dam":
+        return scenes.dam_break(40, 24)
+    if name == "sloshing":  # fluid with a strong x-velocity: many particles cross slab boundaries
+        p, a = scenes.dam_break(36, 20)
+        a["vel"][:, 0] = 4.0
+        a["pos"][:, 0] += np.float32(2.0)
+        return p, a
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("world,scene,nsteps,rebalance_every", [(2, "dam", 6, 0), (3, "sloshing", 40, 0),
+                                                                 (2, "sloshing", 30, 7)])
+def test_slab_equals_single_domain(tmp_path, world, scene, nsteps, rebalance_every):
+    out = str(tmp_path / "got.npy")
+    mp.spawn(_worker, args=(world, _free_port(), scene, nsteps, rebalance_every, out), nprocs=world, join=True)
+    got = np.load(out)
+    params, a = _scene(scene)
+    want = orc.Oracle().step_cells(params, a.copy(), nsteps)
+    assert orc.same_bits(got, want)
+
+
+def test_balanced_bounds():
+    hist = np.zeros(100, np.int64)
+    hist[:25] = 40  # dam break: all the fluid in the left quarter
+    b = balanced_bounds(hist, 4)
+    assert b[0] == 0 and b[-1] == 100 and all(b[i + 1] - b[i] >= 3 for i in range(4))
+    loads = [hist[b[i]:b[i + 1]].sum() for i in range(4)]
+    assert max(loads) <= 1.3 * hist.sum() / 4
+    # clamped moves: every new boundary stays between its old neighbours
+    prev = [0, 10, 20, 30, 100]
+    nb = balanced_bounds(hist, 4, prev=prev)
+    for g in range(1, 4):
+        assert prev[g - 1] + 3 <= nb[g] <= prev[g + 1] - 3
+    with pytest.raises(ValueError):
+        balanced_bounds(np.ones(11), 4)
+
+
+def test_grid_column_matches_oracle_keys():
+    params, a = scenes.dam_break(30, 30)
+    O = orc.Oracle()
+    keys, _, _, _ = O.build_cells(params, a)
+    drv = _lib.derive(params)
+    assert np.array_equal(grid_column(a["pos"][:, 0], params, drv), keys // drv.ny)
+
+
+def test_sharded_scene_equals_global_scene():
+    params, a = scenes.dam_break(50, 30)
+    p2, n_total, hist_fn, make_local = scenes.dam_break_sharded(50, 30)
+    assert bytes(p2) == bytes(params) and n_total == len(a)
+    drv = _lib.derive(params)
+    hist = hist_fn(drv)
+    assert hist.sum() == n_total
+    assert np.array_equal(hist, np.bincount(grid_column(a["pos"][:, 0], params, drv), minlength=drv.nx))
+    b = balanced_bounds(hist, 3)
+    seen = np.zeros(n_total, int)
+    for g in range(3):
+        la, ids = make_local(b[g], b[g + 1], drv)
+        assert orc.same_bits(la, a[ids])
+        seen[ids] += 1
+    assert np.all(seen == 1)
