@@ -117,7 +117,8 @@ def main():
     name = args.workload or "dam1m"
     kind, cols, rows = WORKLOADS[name]
 
-    if world == 1:
+    force_slab = os.environ.get("SPH_BENCH_FORCE_SLAB") == "1"  # exercise the slab path on one GPU
+    if world == 1 and not force_slab:
         params, a = scenes.dam_break(cols, rows) if kind == "dam" else scenes.uniform_box(cols)
         n_total = len(a)
         solver = Solver(params, n_max=n_total, device=local_rank)
@@ -145,7 +146,8 @@ def main():
 
     step(args.warmup)
     sync()
-    inner = solver if world == 1 else solver.solver
+    slabbed = world > 1 or force_slab
+    inner = solver.solver if slabbed else solver
     inner.set_profiling(True)
     inner.reset_phase_times()
     barrier()
@@ -172,7 +174,7 @@ def main():
         elapsed = float(t.item())
 
     # neighbour statistics, off the timed path
-    if world > 1:
+    if slabbed:
         inner.drop_ghosts()
         inner.set_owned_columns(0, drv.nx)  # count over this rank's own particles only (edge pairs are missed)
     inner.computeDensityPressure()
@@ -242,7 +244,7 @@ def main():
             out.update(extra)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if slabbed:
         import torch.distributed as dist
 
         dist.barrier()
