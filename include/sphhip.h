@@ -189,6 +189,12 @@ int sphhip_append(SphCtx* ctx, const void* d_records, int n);
  * count-balanced slab boundaries. */
 int sphhip_column_histogram(SphCtx* ctx, int* hist);
 
+/* Self-test of the library's own correctly rounded reciprocal / division sequences
+ * (sph_amd/csrc/exact_div.h) against the compiler's IEEE `/` on the GPU: every float of the safe
+ * range for 1/x, 2^31 random pairs for a/b.  No counterpart in the reference (it divides with `/`,
+ * SPH/sph.cpp:18,31,69,72); this is what licenses the cheaper sequence to claim the same bits. */
+int sphhip_selftest_division(int device, unsigned long long* checked, unsigned long long* mismatches);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 enum {

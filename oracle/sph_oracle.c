@@ -424,20 +424,21 @@ void orc_build_cells(const SphParams* p, const orc_particle* a, int n, int* keys
     free(ki);
 }
 
-/* Canonical neighbour order of the HIP path, for the particle in cell (cx,cy): columns cx-1, cx,
- * cx+1 (skipping columns outside the grid); within a column the contiguous slot range of cells
- * cy-1..cy+1 (clamped) in ascending slot order.  `lo/hi` receive up to three half-open ranges. */
-static inline int orc_stencil_ranges(const int* cell_start, int nx, int ny, int cx, int cy, int lo[3], int hi[3]) {
+/* Canonical neighbour order of the HIP path, for the particle in cell (cx,cy): cell rows cy-1, cy,
+ * cy+1 (clamped to the grid); inside a row the cells of columns cx-1, cx, cx+1 (skipping columns
+ * outside the grid); inside a cell ascending slot.  `lo/hi` receive up to nine half-open ranges. */
+static inline int orc_stencil_ranges(const int* cell_start, int nx, int ny, int cx, int cy, int lo[9], int hi[9]) {
     int nr = 0;
     int y0 = cy > 0 ? cy - 1 : 0;
     int y1 = cy < ny - 1 ? cy + 1 : ny - 1;
-    for (int dc = -1; dc <= 1; dc++) {
-        int c = cx + dc;
-        if (c < 0 || c >= nx) continue;
-        lo[nr] = cell_start[c * ny + y0];
-        hi[nr] = cell_start[c * ny + y1 + 1];
-        nr++;
-    }
+    for (int y = y0; y <= y1; y++)
+        for (int dc = -1; dc <= 1; dc++) {
+            int c = cx + dc;
+            if (c < 0 || c >= nx) continue;
+            lo[nr] = cell_start[c * ny + y];
+            hi[nr] = cell_start[c * ny + y + 1];
+            nr++;
+        }
     return nr;
 }
 
@@ -456,7 +457,7 @@ void orc_density_cells(const SphParams* p, orc_particle* a, int n, int* counts) 
 #pragma omp parallel for schedule(dynamic, 256)
     for (int i = 0; i < n; i++) {
         int cx = keys[i] / ny, cy = keys[i] % ny;
-        int lo[3], hi[3];
+        int lo[9], hi[9];
         int nr = orc_stencil_ranges(cs, nx, ny, cx, cy, lo, hi);
         float dens = 0.0f;
         int cnt = 0;
@@ -500,7 +501,7 @@ void orc_forces_cells(const SphParams* p, orc_particle* a, int n, float mx, floa
         nvy[i] = a[i].vy;
         if (!a[i].valid) continue;
         int cx = keys[i] / ny, cy = keys[i] % ny;
-        int lo[3], hi[3];
+        int lo[9], hi[9];
         int nr = orc_stencil_ranges(cs, nx, ny, cx, cy, lo, hi);
         float fx = 0.0f, fy = 0.0f;
         for (int r = 0; r < nr; r++)

@@ -182,6 +182,18 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
         int v = atoi(e);
         if (v >= 1 && v <= PAIR_MAX_TILE_CELLS) c->tile_cells = v;
     }
+    {   // exact_div.h needs every numerator of the pair force inside its safe range
+        // inside [SPH_SAFE_LO, SPH_SAFE_HI] of exact_div.h with margin
+        auto safe = [](float x) { x = std::fabs(x); return x >= 4e-12f && x <= 2.5e11f; };
+        float t = p->h;  // term = h - r_len <= h
+        c->fast_div = safe(d.spiky * t * t) && safe(d.visc_mass * d.visc_lap * t) && safe(p->h) && safe(p->stiffness) &&
+                      safe(p->rest_density) && safe(d.spiky * 1e-8f * 1e-8f) && safe(d.visc_mass * d.visc_lap * 1e-8f);
+        if (const char* e = getenv("SPHHIP_FAST_DIV")) c->fast_div = c->fast_div && atoi(e) != 0;
+    }
+    if (const char* e = getenv("SPHHIP_PAIR_THREADS")) {
+        int v = atoi(e);
+        if (v == 128 || v == 256) c->pair_threads = v;
+    }
     if (const char* e = getenv("SPHHIP_PAIR_CAP")) {
         int v = atoi(e);
         if (v >= 64 && v <= 6144) c->pair_cap = v;
@@ -248,6 +260,7 @@ extern "C" int sphhip_set_tuning(SphCtx* c, int tile_cells, int pair_cap) {
         if (tile_cells > PAIR_MAX_TILE_CELLS) return fail(SPHHIP_EINVAL, "tile_cells too large");
         c->tile_cells = tile_cells;
     }
+    if (3 * (c->tile_cells + 2) > c->pair_threads) c->pair_threads = 256;  // one thread per candidate cell
     if (pair_cap > 0) {
         if (pair_cap < 64 || pair_cap > 6144) return fail(SPHHIP_EINVAL, "pair_cap out of range [64, 6144]");
         c->pair_cap = pair_cap;
@@ -641,6 +654,11 @@ extern "C" int sphhip_column_histogram(SphCtx* c, int* hist) {
     HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(int) * (size_t)c->dc.nx, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SPHHIP_OK;
+}
+
+extern "C" int sphhip_selftest_division(int device, unsigned long long* checked, unsigned long long* mismatches) {
+    if (!checked || !mismatches) return fail(SPHHIP_EINVAL, "null argument");
+    return sph_selftest_division(device, checked, mismatches);
 }
 
 // ---- measurement ----------------------------------------------------------------------------

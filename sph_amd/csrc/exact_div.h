@@ -1,0 +1,44 @@
+// exact_div.h -- correctly rounded fp32 reciprocal / division built on v_rcp_f32 + FMA corrections,
+// for operands in a "safe" range (no overflow / underflow of quotient or remainders).
+//
+// hipcc's generic `a / b` (correctly rounded, any operands) costs ~44 cycles per wave on gfx950:
+// 2 v_div_scale, v_rcp, 6 FMAs, v_div_fmas, v_div_fixup.  The pair force needs four divisions per
+// in-range pair, two of them by r_len and two by rho_j, so sharing one reciprocal per denominator
+// and skipping the range scaling saves ~100 of ~400 cycles per pair.  The sequences below are the
+// hardware expansion minus the scaling: Newton step on the reciprocal, then two remainder
+// corrections of the quotient (Markstein).  They are NOT assumed correct: sphhip_selftest_division
+// (ctx.hip) checks them on the GPU against `1.0f / x` for EVERY float in the safe range and against
+// `a / b` for 2^31 random pairs, and tests/test_gpu_parity.py keeps the whole step bit-exact against
+// the oracle.  Special denominators (0, inf, NaN) go through v_div_fixup like the generic path.
+// Outside the safe range (checked per tile when candidates are staged) the kernel uses plain `/`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// safe range for denominators and non-zero numerators: [2^-40, 2^40]
+#define SPH_SAFE_LO 9.094947017729282e-13f
+#define SPH_SAFE_HI 1.099511627776e12f
+
+__device__ __forceinline__ bool sph_safe_operand(float x) {  // 0 is a safe numerator too
+    float a = fabsf(x);
+    return (a == 0.0f) || (a >= SPH_SAFE_LO && a <= SPH_SAFE_HI);
+}
+
+// refined reciprocal (not yet guaranteed correctly rounded: use sph_rcp_exact for a result)
+__device__ __forceinline__ float sph_rcp_refined(float b) {
+    float y0 = __builtin_amdgcn_rcpf(b);          // <= 1 ulp
+    float e = __builtin_fmaf(-b, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+
+// a / b given y ~ 1/b (refined): two remainder corrections, then special-case fixup
+__device__ __forceinline__ float sph_div_with_rcp(float a, float b, float y) {
+    float q0 = a * y;
+    float r0 = __builtin_fmaf(-b, q0, a);
+    float q1 = __builtin_fmaf(r0, y, q0);
+    float r1 = __builtin_fmaf(-b, q1, a);
+    float q2 = __builtin_fmaf(r1, y, q1);
+    return __builtin_amdgcn_div_fixupf(q2, b, a);
+}
+
+// 1.0f / b
+__device__ __forceinline__ float sph_rcp_exact(float b, float y) { return sph_div_with_rcp(1.0f, b, y); }

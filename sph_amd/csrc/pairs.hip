@@ -7,72 +7,128 @@
 //   integrate         serial_integrate               SPH/sph.cpp:101-130
 // The only difference from the serial loop is the one every parallel variant of the reference has
 // (SPH/MPI_sph.cpp:144-147,181): neighbour velocities come from the state before the force pass.
-// The j-sum of each particle runs sequentially in the canonical neighbour order (columns cx-1, cx,
-// cx+1; inside a column the contiguous slot range of cells cy-1..cy+1), which is also the order of
-// oracle/sph_oracle.c's cell-list functions: the two agree bit for bit.
+// The j-sum of each particle runs sequentially in the canonical neighbour order (cell rows cy-1, cy,
+// cy+1; inside a row the cells of columns cx-1, cx, cx+1; inside a cell ascending slot), which is
+// also the order of oracle/sph_oracle.c's cell-list functions: the two agree bit for bit.
 //
 // Work decomposition: one workgroup per tile = `tile_cells` consecutive cells of one grid column.
-// With column-major keys the tile's particles are one contiguous slot range, and its neighbour
-// candidates are three contiguous slot ranges (one per column), staged once in LDS as SoA records
-// and read by every lane of the tile.  Lanes of one cell read the same LDS addresses (broadcast).
-// If a tile's candidates exceed the LDS budget the same loops read global memory instead.
+// With column-major keys the tile's particles are one contiguous slot range (coalesced SoA loads);
+// its neighbour candidates (three columns, rows +-1) are staged once in LDS as SoA records in
+// row-major cell order, which makes every particle's 3x3 stencil one contiguous LDS range.  Lanes of
+// one cell scan the same LDS addresses (broadcast).  If a tile's candidates exceed the LDS budget
+// the same sums read global memory instead.
 // No MFMA: the pair sums are irregular, distance-predicated gathers, not a contraction.
 #include "sphhip_internal.h"
+#include "exact_div.h"
 
+// ---------------------------------------------------------------------------------------------
+// Tile = `tile_cells` consecutive cells [cy0, cy1) of grid column `col`.  Its neighbour candidates
+// are the cells of rows [ylo, yhi) in columns col-1, col, col+1.  They are staged in LDS in
+// ROW-MAJOR cell order (row y: cells (col-1,y), (col,y), (col+1,y); ascending slot inside a cell),
+// so the 3x3 stencil of a particle in row cy is ONE contiguous LDS range: rows cy-1..cy+1.
+// That order -- rows cy-1, cy, cy+1; inside a row columns cx-1, cx, cx+1; inside a cell ascending
+// slot -- is the canonical summation order, shared with oracle/sph_oracle.c (orc_stencil_ranges).
+//
 // All LDS of the pair kernels is one dynamic array (16-byte aligned base, no static __shared__ in
-// front of it): [float4 aux[cap]] [float2 pos[cap]] [int cs[3][CS_STRIDE]].
-constexpr int CS_STRIDE = PAIR_MAX_TILE_CELLS + 3;
+// front of it): [float4 aux[cap]] (force only) [float2 pos[cap]] [int off[MAXC+1]] [int gs[MAXC]]
+// [int wave_tmp[4]] [u16 queue[QCAP*256]] (force only).
+// ---------------------------------------------------------------------------------------------
+constexpr int PAIR_MAXC = 3 * (PAIR_MAX_TILE_CELLS + 2);  // candidate cells of a tile (<= 256)
+#ifndef FORCE_Q
+#define FORCE_Q 16  // in-range neighbours gathered per round
+#endif
+#ifndef FORCE_SCAN_UNROLL
+#define FORCE_SCAN_UNROLL 4
+#endif
+#ifndef FORCE_HEAVY_UNROLL
+#define FORCE_HEAVY_UNROLL 4
+#endif
+constexpr int FORCE_QCAP = FORCE_Q + FORCE_SCAN_UNROLL + FORCE_HEAVY_UNROLL;  // pushes overshoot by < SCAN_UNROLL, reads by < HEAVY_UNROLL
 
 struct TileGeom {
-    int col;          // grid column of the tile
-    int cy0, cy1;     // owned cells [cy0, cy1)
-    int ylo, yhi;     // candidate cells [ylo, yhi)
-    int own_lo, own_hi;
-    int g_lo[3], len[3], base[3];  // candidate slot ranges per column and their LDS offsets
-    int total;
+    int col, cy0, cy1, ylo, yhi, own_lo, own_hi, ncells, total;
 };
 
-__device__ __forceinline__ void tile_geometry(const DevConsts& c, const int* __restrict__ cell_start, int col,
-                                              int trow, int tile_cells, TileGeom& g) {
+static size_t pair_lds_bytes(int cap, bool force, int threads) {
+    size_t b = sizeof(float2) * (size_t)cap + sizeof(int) * (2 * PAIR_MAXC + 1 + 4);
+    if (force) b += sizeof(float4) * (size_t)cap + sizeof(unsigned short) * FORCE_QCAP * threads;
+    return b;
+}
+
+// Exclusive scan of one int per thread over the workgroup of THREADS threads (two barriers).
+template <int THREADS>
+__device__ __forceinline__ int wg_excl_scan(int v, int* lds_wave, int& total) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) lds_wave[wave] = incl;
+    __syncthreads();
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++) {
+        int x = lds_wave[w];
+        off += (w < wave) ? x : 0;
+        total += x;
+    }
+    __syncthreads();
+    return off + incl - v;
+}
+
+// Fills g, s_off[0..ncells] (LDS start of every candidate cell, row-major) and s_gs[0..ncells)
+// (global slot start of every candidate cell).  Returns false for an empty tile (uniform).
+template <int THREADS>
+__device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __restrict__ cell_start, int col, int trow,
+                                           int tile_cells, TileGeom& g, int* s_off, int* s_gs, int* s_wave) {
     g.col = col;
     g.cy0 = trow * tile_cells;
     g.cy1 = min(g.cy0 + tile_cells, c.ny);
     g.ylo = max(g.cy0 - 1, 0);
     g.yhi = min(g.cy1 + 1, c.ny);
-    g.own_lo = cell_start[g.col * c.ny + g.cy0];
-    g.own_hi = cell_start[g.col * c.ny + g.cy1];
-    g.total = 0;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        int cc = g.col - 1 + d;
-        bool ok = (cc >= 0) && (cc < c.nx);
-        int lo = ok ? cell_start[cc * c.ny + g.ylo] : 0;
-        int hi = ok ? cell_start[cc * c.ny + g.yhi] : 0;
-        g.g_lo[d] = lo;
-        g.len[d] = hi - lo;
-        g.base[d] = g.total;
-        g.total += hi - lo;
+    g.own_lo = cell_start[col * c.ny + g.cy0];
+    g.own_hi = cell_start[col * c.ny + g.cy1];
+    if (g.own_lo == g.own_hi) return false;
+    g.ncells = 3 * (g.yhi - g.ylo);
+    int t = threadIdx.x;
+    int cnt = 0, g0 = 0;
+    if (t < g.ncells) {
+        int row = t / 3, d = t - 3 * row;
+        int cc = col - 1 + d;
+        if (cc >= 0 && cc < c.nx) {
+            int key = cc * c.ny + g.ylo + row;
+            g0 = cell_start[key];
+            cnt = cell_start[key + 1] - g0;
+        }
     }
-}
-
-// Stage the cell_start entries of the three candidate columns: s_cs[d][t] = cell_start of cell
-// (col-1+d, ylo+t), t = 0..(yhi-ylo) inclusive.
-__device__ __forceinline__ void stage_cell_starts(const DevConsts& c, const int* __restrict__ cell_start,
-                                                  const TileGeom& g, int* s_cs) {
-    int rows = g.yhi - g.ylo + 1;
-    for (int t = threadIdx.x; t < 3 * rows; t += PAIR_THREADS) {
-        int d = t / rows, y = t - d * rows;
-        int cc = g.col - 1 + d;
-        bool ok = (cc >= 0) && (cc < c.nx);
-        s_cs[d * CS_STRIDE + y] = ok ? cell_start[cc * c.ny + g.ylo + y] : 0;
+    int ex = wg_excl_scan<THREADS>(cnt, s_wave, g.total);
+    if (t < g.ncells) {
+        s_off[t] = ex;
+        s_gs[t] = g0;
     }
+    if (t == 0) s_off[g.ncells] = g.total;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
 // density + pressure + neighbour count.   Algorithmic HBM bytes / particle: R pos 8, W rho 4 + P 4
 // (+ 4 for the neighbour count) = 16 (+4).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PAIR_THREADS) void k_density(DevConsts c, const float2* __restrict__ pos,
+__device__ __forceinline__ void density_acc(const DevConsts& c, float2 pi, float2 q, float& dens, int& cnt) {
+    float rx = pi.x - q.x, ry = pi.y - q.y;
+    float r2 = rx * rx + ry * ry;
+    float term = c.h2 - r2;
+    float w = c.mass * (c.poly6 * term * term * term);  // MASS * poly6(r2, H), sph.cpp:11,49
+    bool in = r2 < c.h2;                                // sph.cpp:48
+    dens += in ? w : 0.0f;                              // x + 0.0f == x: same bits as the branch
+    cnt += in ? 1 : 0;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* __restrict__ pos,
                                                            const uint32_t* __restrict__ skeys,
                                                            const int* __restrict__ cell_start,
                                                            float* __restrict__ rho, float* __restrict__ prs,
@@ -80,55 +136,36 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_density(DevConsts c, const flo
                                                            int tiles_per_col, int tile_cells, int cap) {
     extern __shared__ __align__(16) float4 s_dyn[];
     float2* s_pos = reinterpret_cast<float2*>(s_dyn);
-    int* s_cs = reinterpret_cast<int*>(s_pos + cap);
+    int* s_off = reinterpret_cast<int*>(s_pos + cap);
+    int* s_gs = s_off + PAIR_MAXC + 1;
+    int* s_wave = s_gs + PAIR_MAXC;
     int tcol, trow;
     if (!sph_tile_of_block(blockIdx.x, ncols, tiles_per_col, tcol, trow)) return;
     TileGeom g;
-    tile_geometry(c, cell_start, col0 + tcol, trow, tile_cells, g);
-    if (g.own_lo == g.own_hi) return;  // uniform: empty tile
+    if (!tile_setup<THREADS>(c, cell_start, col0 + tcol, trow, tile_cells, g, s_off, s_gs, s_wave)) return;
+    __syncthreads();
     const bool use_lds = g.total <= cap;
     if (use_lds) {
-#pragma unroll
-        for (int d = 0; d < 3; d++)
-            for (int t = threadIdx.x; t < g.len[d]; t += PAIR_THREADS) s_pos[g.base[d] + t] = pos[g.g_lo[d] + t];
+        // 16 lanes per candidate cell, 16 cells per pass
+        for (int cc = threadIdx.x >> 4; cc < g.ncells; cc += THREADS / 16) {
+            int o = s_off[cc], n = s_off[cc + 1] - o, gs = s_gs[cc];
+            for (int k = threadIdx.x & 15; k < n; k += 16) s_pos[o + k] = pos[gs + k];
+        }
+        __syncthreads();
     }
-    stage_cell_starts(c, cell_start, g, s_cs);
-    __syncthreads();
-
-    for (int s = g.own_lo + (int)threadIdx.x; s < g.own_hi; s += PAIR_THREADS) {
+    for (int s = g.own_lo + (int)threadIdx.x; s < g.own_hi; s += THREADS) {
         const float2 pi = pos[s];
         const int cy = (int)skeys[s] - g.col * c.ny;
-        const int y0 = max(cy - 1, 0) - g.ylo;
-        const int y1 = min(cy + 1, c.ny - 1) + 1 - g.ylo;
+        const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
         float dens = 0.0f;
         int cnt = 0;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            if (g.len[d] == 0) continue;
-            int lo = s_cs[d * CS_STRIDE + y0], hi = s_cs[d * CS_STRIDE + y1];
-            if (use_lds) {
-                int off = g.base[d] - g.g_lo[d];
-                for (int j = lo + off; j < hi + off; j++) {
-                    float2 q = s_pos[j];
-                    float rx = pi.x - q.x, ry = pi.y - q.y;
-                    float r2 = rx * rx + ry * ry;
-                    float term = c.h2 - r2;
-                    float w = c.mass * (c.poly6 * term * term * term);  // MASS * poly6(r2, H), sph.cpp:11,49
-                    bool in = r2 < c.h2;                                // sph.cpp:48
-                    dens += in ? w : 0.0f;                              // x + 0.0f == x: same bits as the branch
-                    cnt += in ? 1 : 0;
-                }
-            } else {
-                for (int j = lo; j < hi; j++) {
-                    float2 q = pos[j];
-                    float rx = pi.x - q.x, ry = pi.y - q.y;
-                    float r2 = rx * rx + ry * ry;
-                    float term = c.h2 - r2;
-                    float w = c.mass * (c.poly6 * term * term * term);
-                    bool in = r2 < c.h2;
-                    dens += in ? w : 0.0f;
-                    cnt += in ? 1 : 0;
-                }
+        if (use_lds) {
+            const int lo = s_off[3 * r0], hi = s_off[3 * r1 + 3];
+            for (int j = lo; j < hi; j++) density_acc(c, pi, s_pos[j], dens, cnt);
+        } else {
+            for (int cc = 3 * r0; cc < 3 * r1 + 3; cc++) {
+                int gs = s_gs[cc], n = s_off[cc + 1] - s_off[cc];
+                for (int j = gs; j < gs + n; j++) density_acc(c, pi, pos[j], dens, cnt);
             }
         }
         float pr = c.stiffness * (dens - c.rest_density);  // sph.cpp:52-53
@@ -140,38 +177,91 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_density(DevConsts c, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
-// One j-term of the force sum, SPH/sph.cpp:64-75.  (rx, ry) = p_i - p_j.
+// U independent j-terms of the force sum, SPH/sph.cpp:64-75, written statement by statement over
+// the U pairs so that their long dependent chains (sqrt, four divisions) interleave in the
+// instruction stream.  (rx, ry) = p_i - p_j.  Every operation is the reference's, in its order.
 // ---------------------------------------------------------------------------------------------
+// FAST: divisions through exact_div.h (operands checked to be in the safe range when the tile was
+// staged); otherwise hipcc's generic correctly rounded `/`.  Same results bit for bit.
+template <int U, bool FAST>
+__device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx)[U], const float (&ry)[U],
+                                            const float (&r2)[U], float pres_i, float vix, float viy,
+                                            const float4 (&aj)[U] /* vx, vy, rho, P of j */, float (&fx)[U],
+                                            float (&fy)[U]) {
+    float r_len[U], gcoeff[U], pt[U], visc[U], inv_r[U], lcoeff[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) r_len[u] = sqrtf(r2[u]);  // sph.cpp:67
+    if (FAST) {
+        float yr[U], yd[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) yr[u] = sph_rcp_refined(r_len[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) yd[u] = sph_rcp_refined(aj[u].z);
+#pragma unroll
+        for (int u = 0; u < U; u++) inv_r[u] = sph_rcp_exact(r_len[u], yr[u]);  // 1.0f / r_len, sph.cpp:31
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float term = c.h - r_len[u];
+            gcoeff[u] = sph_div_with_rcp(c.spiky * term * term, r_len[u], yr[u]);  // sph.cpp:17-18
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)  // (P_i + P_j) / (2 rho_j) == ((P_i + P_j) / rho_j) / 2 exactly in the safe range
+            pt[u] = 0.5f * sph_div_with_rcp(pres_i + aj[u].w, aj[u].z, yd[u]);  // sph.cpp:69
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float lap = (r_len[u] > c.h) ? 0.0f : c.visc_lap * (c.h - r_len[u]);  // sph.cpp:23-26
+            visc[u] = sph_div_with_rcp(c.visc_mass * lap, aj[u].z, yd[u]);         // sph.cpp:72
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) inv_r[u] = 1.0f / r_len[u];  // sph.cpp:31
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float term = c.h - r_len[u];
+            gcoeff[u] = c.spiky * term * term / r_len[u];  // sph.cpp:17-18
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) pt[u] = (pres_i + aj[u].w) / (2.0f * aj[u].z);  // sph.cpp:69
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float lap = (r_len[u] > c.h) ? 0.0f : c.visc_lap * (c.h - r_len[u]);  // sph.cpp:23-26
+            visc[u] = c.visc_mass * lap / aj[u].z;                                 // sph.cpp:72
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {  // Lennard-Jones, sph.cpp:32-37
+        float sr = c.sigma * inv_r[u];
+        float sr2 = sr * sr;
+        float sr6 = sr2 * sr2 * sr2;
+        float sr12 = sr6 * sr6;
+        float inv_r2 = inv_r[u] * inv_r[u];
+        lcoeff[u] = c.lj24 * (2.0f * sr12 - sr6) * inv_r2;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        // spiky gradient guard, sph.cpp:16.  `r_len < 1e-6` there is a double compare: true for
+        // r_len <= 1e-6f (the float just below 1e-6), false from the next float up.
+        bool zero_grad = (r_len[u] > c.h) || (r_len[u] <= 1e-6f);
+        float gx = zero_grad ? 0.0f : gcoeff[u] * rx[u];
+        float gy = zero_grad ? 0.0f : gcoeff[u] * ry[u];
+        float pfx = c.neg_mass * pt[u] * gx;  // sph.cpp:70
+        float pfy = c.neg_mass * pt[u] * gy;
+        float relx = aj[u].x - vix, rely = aj[u].y - viy;  // sph.cpp:71
+        bool zero_lj = (r_len[u] >= c.lj_cut) || (r_len[u] < 1e-6f);  // sph.cpp:30
+        float ljx = zero_lj ? 0.0f : lcoeff[u] * rx[u];
+        float ljy = zero_lj ? 0.0f : lcoeff[u] * ry[u];
+        fx[u] = pfx + visc[u] * relx + ljx;  // sph.cpp:74-75 (the caller adds it to force)
+        fy[u] = pfy + visc[u] * rely + ljy;
+    }
+}
+
 __device__ __forceinline__ void force_term(const DevConsts& c, float rx, float ry, float r2, float pres_i,
-                                           float vix, float viy, float4 aj /* vx, vy, rho, P of j */, float& fx,
-                                           float& fy) {
-    float r_len = sqrtf(r2);                                   // sph.cpp:67
-    // spiky gradient, sph.cpp:15-20.  `r_len < 1e-6` there is a double compare: true for
-    // r_len <= 1e-6f (the float below 1e-6), false from the next float up.
-    bool zero_grad = (r_len > c.h) || (r_len <= 1e-6f);
-    float term = c.h - r_len;
-    float gcoeff = c.spiky * term * term / r_len;
-    float gx = zero_grad ? 0.0f : gcoeff * rx;
-    float gy = zero_grad ? 0.0f : gcoeff * ry;
-    float pressureTerm = (pres_i + aj.w) / (2.0f * aj.z);     // sph.cpp:69
-    float pfx = c.neg_mass * pressureTerm * gx;                // sph.cpp:70
-    float pfy = c.neg_mass * pressureTerm * gy;
-    float relx = aj.x - vix, rely = aj.y - viy;                // sph.cpp:71
-    float lap = (r_len > c.h) ? 0.0f : c.visc_lap * (c.h - r_len);  // sph.cpp:23-26
-    float viscForce = c.visc_mass * lap / aj.z;                // sph.cpp:72
-    // Lennard-Jones, sph.cpp:29-39
-    bool zero_lj = (r_len >= c.lj_cut) || (r_len < 1e-6f);
-    float inv_r = 1.0f / r_len;
-    float sr = c.sigma * inv_r;
-    float sr2 = sr * sr;
-    float sr6 = sr2 * sr2 * sr2;
-    float sr12 = sr6 * sr6;
-    float inv_r2 = inv_r * inv_r;
-    float lcoeff = c.lj24 * (2.0f * sr12 - sr6) * inv_r2;
-    float ljx = zero_lj ? 0.0f : lcoeff * rx;
-    float ljy = zero_lj ? 0.0f : lcoeff * ry;
-    fx += pfx + viscForce * relx + ljx;                        // sph.cpp:74-75
-    fy += pfy + viscForce * rely + ljy;
+                                           float vix, float viy, float4 aj, float& fx, float& fy) {
+    float a[1] = {rx}, b[1] = {ry}, d[1] = {r2}, ox[1], oy[1];
+    float4 e[1] = {aj};
+    force_terms<1, false>(c, a, b, d, pres_i, vix, viy, e, ox, oy);
+    fx = ox[0];
+    fy = oy[0];
 }
 
 // Everything after the j loop of serial_computeForces (sph.cpp:77-97) and, when FUSE, the body of
@@ -235,8 +325,11 @@ __device__ __forceinline__ void integrate_one(const DevConsts& c, float2& p, flo
 // Tiles whose column is outside [own_lo_col, own_hi_col) only pass their particles through
 // (ghost columns of a slab).
 // ---------------------------------------------------------------------------------------------
-template <bool FUSE>
-__global__ __launch_bounds__(PAIR_THREADS) void k_force(DevConsts c, const float2* __restrict__ pos,
+#ifndef FORCE_WAVES_MAX
+#define FORCE_WAVES_MAX 4
+#endif
+template <bool FUSE, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORCE_WAVES_MAX))) void k_force(DevConsts c, const float2* __restrict__ pos,
                                                          const float2* __restrict__ vel,
                                                          const float* __restrict__ rho,
                                                          const float* __restrict__ prs,
@@ -246,90 +339,167 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_force(DevConsts c, const float
                                                          float2* __restrict__ pos_o, float2* __restrict__ vel_o,
                                                          int col0, int ncols, int tiles_per_col, int tile_cells,
                                                          int cap, int own_lo_col, int own_hi_col, float mx, float my,
-                                                         float strength) {
-    extern __shared__ __align__(16) float4 s_dyn[];  // [cap] float4 aux, [cap] float2 pos, cell starts
+                                                         float strength, int allow_fast) {
+    extern __shared__ __align__(16) float4 s_dyn[];
     float4* s_aux = s_dyn;
     float2* s_pos = reinterpret_cast<float2*>(s_dyn + cap);
-    int* s_cs = reinterpret_cast<int*>(s_pos + cap);
+    int* s_off = reinterpret_cast<int*>(s_pos + cap);
+    int* s_gs = s_off + PAIR_MAXC + 1;
+    int* s_wave = s_gs + PAIR_MAXC;
+    unsigned short* s_q = reinterpret_cast<unsigned short*>(s_wave + 4);
 
     int tcol, trow;
     if (!sph_tile_of_block(blockIdx.x, ncols, tiles_per_col, tcol, trow)) return;
-    TileGeom g;
-    tile_geometry(c, cell_start, col0 + tcol, trow, tile_cells, g);
-    if (g.own_lo == g.own_hi) return;
-    if (g.col < own_lo_col || g.col >= own_hi_col) {  // ghost column: pass through
-        for (int s = g.own_lo + (int)threadIdx.x; s < g.own_hi; s += PAIR_THREADS) {
-            vel_o[s] = vel[s];
-            if (FUSE) pos_o[s] = pos[s];
+    {   // ghost column of a slab: pass the particles through (cheap test before any setup)
+        int col = col0 + tcol;
+        if (col < own_lo_col || col >= own_hi_col) {
+            int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
+            int lo = cell_start[col * c.ny + cy0], hi = cell_start[col * c.ny + cy1];
+            for (int s = lo + (int)threadIdx.x; s < hi; s += THREADS) {
+                vel_o[s] = vel[s];
+                if (FUSE) pos_o[s] = pos[s];
+            }
+            return;
         }
-        return;
     }
+    TileGeom g;
+    if (!tile_setup<THREADS>(c, cell_start, col0 + tcol, trow, tile_cells, g, s_off, s_gs, s_wave)) return;
+    __syncthreads();
     const bool use_lds = g.total <= cap;
     const float inf = __builtin_inff();
+    bool fast = false;
     if (use_lds) {
-#pragma unroll
-        for (int d = 0; d < 3; d++)
-            for (int t = threadIdx.x; t < g.len[d]; t += PAIR_THREADS) {
-                int j = g.g_lo[d] + t;
+        int unsafe = allow_fast ? 0 : 1;
+        for (int cc = threadIdx.x >> 4; cc < g.ncells; cc += THREADS / 16) {
+            int o = s_off[cc], n = s_off[cc + 1] - o, gs = s_gs[cc];
+            for (int k = threadIdx.x & 15; k < n; k += 16) {
+                int j = gs + k;
                 float2 q = pos[j];
                 float2 w = vel[j];
+                float dj = rho[j], pj = prs[j];
+                // exact_div.h is used only if every density / pressure of the tile is in its safe range
+                unsafe |= (dj == 0.0f || !sph_safe_operand(dj) || !sph_safe_operand(pj)) ? 1 : 0;
                 // `!particles[j].valid` (sph.cpp:63): an invalid j is staged at +inf so that
                 // r2 = +inf >= H*H skips it with the same compare that skips far particles.
                 if (idv[j] & SPH_INVALID_BIT) q = make_float2(inf, inf);
-                s_pos[g.base[d] + t] = q;
-                s_aux[g.base[d] + t] = make_float4(w.x, w.y, rho[j], prs[j]);
+                s_pos[o + k] = q;
+                s_aux[o + k] = make_float4(w.x, w.y, dj, pj);
             }
-    }
-    stage_cell_starts(c, cell_start, g, s_cs);
-    __syncthreads();
-
-    for (int s = g.own_lo + (int)threadIdx.x; s < g.own_hi; s += PAIR_THREADS) {
-        float2 pi = pos[s];
-        float2 vi = vel[s];
-        if (idv[s] & SPH_INVALID_BIT) {  // sph.cpp:59,103: invalid particles are left alone
-            vel_o[s] = vi;
-            if (FUSE) pos_o[s] = pi;
-            continue;
         }
-        const float dens_i = rho[s], pres_i = prs[s];
-        const int cy = (int)skeys[s] - g.col * c.ny;
-        const int y0 = max(cy - 1, 0) - g.ylo;
-        const int y1 = min(cy + 1, c.ny - 1) + 1 - g.ylo;
+        fast = !__syncthreads_or(unsafe);
+    }
+
+    // All lanes of a wave stay in the loop together (wave-level votes below); lanes without a
+    // particle, or with an invalid one, simply have an empty candidate range.
+    const int n_iter = (g.own_hi - g.own_lo + THREADS - 1) / THREADS;
+    for (int it = 0; it < n_iter; it++) {
+        const int s = g.own_lo + it * THREADS + (int)threadIdx.x;
+        const bool have = s < g.own_hi;
+        float2 pi = make_float2(0.0f, 0.0f), vi = pi;
+        float dens_i = 1.0f, pres_i = 0.0f;
+        bool valid = false;
+        int r0 = 0, r1 = -1, self_cell = 0;
+        if (have) {
+            pi = pos[s];
+            vi = vel[s];
+            valid = !(idv[s] & SPH_INVALID_BIT);
+            dens_i = rho[s];
+            pres_i = prs[s];
+            const int cy = (int)skeys[s] - g.col * c.ny;
+            r0 = max(cy - 1, 0) - g.ylo;
+            r1 = min(cy + 1, c.ny - 1) - g.ylo;
+            self_cell = 3 * (cy - g.ylo) + 1;
+        }
         float fx = 0.0f, fy = 0.0f;
+        if (use_lds) {
+            int j = 0, hi = 0, self = -1;
+            if (have && valid) {  // sph.cpp:59: invalid particles get no force
+                j = s_off[3 * r0];
+                hi = s_off[3 * r1 + 3];
+                self = s_off[self_cell] + (s - s_gs[self_cell]);
+            }
+            // Rounds: (1) every lane scans its candidates until it has gathered FORCE_Q in-range
+            // neighbours (cheap test, indices queued in LDS in scan order); (2) all lanes evaluate
+            // their queued pairs together.  The expensive pair arithmetic then runs with (nearly)
+            // all lanes active instead of being predicated on a per-candidate distance test.
+            while (__any(j < hi)) {
+                int qn = 0;
+                while (__any((j < hi) && (qn < FORCE_Q))) {
+                    if ((j < hi) && (qn < FORCE_Q)) {
+                        float2 q[FORCE_SCAN_UNROLL];
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            if (g.len[d] == 0) continue;
-            int lo = s_cs[d * CS_STRIDE + y0], hi = s_cs[d * CS_STRIDE + y1];
-            if (use_lds) {
-                int off = g.base[d] - g.g_lo[d];
-                int self = (d == 1) ? s + off : -1;
-                for (int j = lo + off; j < hi + off; j++) {
-                    float2 q = s_pos[j];
-                    float rx = pi.x - q.x, ry = pi.y - q.y;
-                    float r2 = rx * rx + ry * ry;
-                    if (!(r2 >= c.h2) && j != self)  // sph.cpp:63,66
-                        force_term(c, rx, ry, r2, pres_i, vi.x, vi.y, s_aux[j], fx, fy);
+                        for (int u = 0; u < FORCE_SCAN_UNROLL; u++) q[u] = s_pos[min(j + u, hi - 1)];
+#pragma unroll
+                        for (int u = 0; u < FORCE_SCAN_UNROLL; u++) {
+                            int jj = j + u;
+                            float rx = pi.x - q[u].x, ry = pi.y - q[u].y;
+                            float r2 = rx * rx + ry * ry;
+                            bool in = (jj < hi) && !(r2 >= c.h2) && (jj != self);  // sph.cpp:63,66
+                            // branch-free push: the slot is rewritten until a candidate is accepted
+                            s_q[qn * THREADS + threadIdx.x] = (unsigned short)jj;
+                            qn += in ? 1 : 0;
+                        }
+                        j += FORCE_SCAN_UNROLL;
+                    }
                 }
-            } else {
-                int self = (d == 1) ? s : -1;
-                for (int j = lo; j < hi; j++) {
+                // FORCE_HEAVY_UNROLL independent pair evaluations in flight per lane (no branches:
+                // a lane past its queue end evaluates a harmless dummy candidate and discards it)
+                for (int t = 0; __any(t < qn); t += FORCE_HEAVY_UNROLL) {
+                    int jj[FORCE_HEAVY_UNROLL];
+                    float tx[FORCE_HEAVY_UNROLL], ty[FORCE_HEAVY_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+                        int e = s_q[(t + u) * THREADS + threadIdx.x];
+                        jj[u] = (t + u < qn) ? e : 0;
+                    }
+                    float rx[FORCE_HEAVY_UNROLL], ry[FORCE_HEAVY_UNROLL], r2[FORCE_HEAVY_UNROLL];
+                    float4 aj[FORCE_HEAVY_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+                        float2 q = s_pos[jj[u]];
+                        aj[u] = s_aux[jj[u]];
+                        rx[u] = pi.x - q.x;
+                        ry[u] = pi.y - q.y;
+                        r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
+                    }
+                    if (fast)  // uniform over the workgroup
+                        force_terms<FORCE_HEAVY_UNROLL, true>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, tx, ty);
+                    else
+                        force_terms<FORCE_HEAVY_UNROLL, false>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, tx, ty);
+                    // same order as the sequential sum: force += term(t); force += term(t+1); ...
+#pragma unroll
+                    for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+                        fx = (t + u < qn) ? fx + tx[u] : fx;
+                        fy = (t + u < qn) ? fy + ty[u] : fy;
+                    }
+                }
+            }
+        } else if (have && valid) {
+            for (int cc = 3 * r0; cc < 3 * r1 + 3; cc++) {
+                int gs = s_gs[cc], n = s_off[cc + 1] - s_off[cc];
+                for (int j = gs; j < gs + n; j++) {
                     float2 q = pos[j];
                     if (idv[j] & SPH_INVALID_BIT) q = make_float2(inf, inf);
                     float rx = pi.x - q.x, ry = pi.y - q.y;
                     float r2 = rx * rx + ry * ry;
-                    if (!(r2 >= c.h2) && j != self) {
+                    if (!(r2 >= c.h2) && j != s) {
                         float2 w = vel[j];
-                        force_term(c, rx, ry, r2, pres_i, vi.x, vi.y, make_float4(w.x, w.y, rho[j], prs[j]), fx, fy);
+                        float ax = 0.0f, ay = 0.0f;
+                        force_term(c, rx, ry, r2, pres_i, vi.x, vi.y, make_float4(w.x, w.y, rho[j], prs[j]), ax, ay);
+                        fx += ax;
+                        fy += ay;
                     }
                 }
             }
         }
-        force_epilogue<FUSE>(c, fx, fy, pi, vi, dens_i, mx, my, strength);
-        if (FUSE) {
-            integrate_one(c, pi, vi);
-            pos_o[s] = pi;
+        if (have) {
+            if (valid) {
+                force_epilogue<FUSE>(c, fx, fy, pi, vi, dens_i, mx, my, strength);
+                if (FUSE) integrate_one(c, pi, vi);
+            }
+            if (FUSE) pos_o[s] = pi;  // sph.cpp:59,103: invalid particles are left alone
+            vel_o[s] = vi;
         }
-        vel_o[s] = vi;
     }
 }
 
@@ -363,10 +533,11 @@ int sph_density_launch(SphCtx* c) {
     int lo = c->col_lo > 0 ? c->col_lo - 1 : 0;
     int hi = c->col_hi < c->dc.nx ? c->col_hi + 1 : c->dc.nx;
     TileMap tm = tile_launch_dims(c, lo, hi);
-    size_t lds = sizeof(float2) * (size_t)c->pair_cap + sizeof(int) * 3 * CS_STRIDE;
-    hipLaunchKernelGGL(k_density, dim3(tm.nblocks), dim3(PAIR_THREADS), lds, c->stream, c->dc, c->pos, c->keys,
-                       c->cell_start, c->rho, c->prs, c->ncount, lo, tm.ncols, tm.tiles_per_col, c->tile_cells,
-                       c->pair_cap);
+    const int th = c->pair_threads;
+    size_t lds = pair_lds_bytes(c->pair_cap, false, th);
+    auto kern = th == 128 ? k_density<128> : k_density<256>;
+    hipLaunchKernelGGL(kern, dim3(tm.nblocks), dim3(th), lds, c->stream, c->dc, c->pos, c->keys, c->cell_start, c->rho,
+                       c->prs, c->ncount, lo, tm.ncols, tm.tiles_per_col, c->tile_cells, c->pair_cap);
     LAUNCH_CHECK();
     c->counts_valid = true;
     return SPHHIP_OK;
@@ -376,21 +547,18 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     if (c->n == 0) return SPHHIP_OK;
     PhaseScope ps(c, SPHHIP_PH_FORCE);
     TileMap tm = tile_launch_dims(c, 0, c->dc.nx);  // all columns: ghost tiles pass through
-    size_t lds = (sizeof(float4) + sizeof(float2)) * (size_t)c->pair_cap + sizeof(int) * 3 * CS_STRIDE;
+    const int th = c->pair_threads;
+    size_t lds = pair_lds_bytes(c->pair_cap, true, th);
+    auto kern = fuse_integrate ? (th == 128 ? k_force<true, 128> : k_force<true, 256>)
+                               : (th == 128 ? k_force<false, 128> : k_force<false, 256>);
+    hipLaunchKernelGGL(kern, dim3(tm.nblocks), dim3(th), lds, c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv,
+                       c->keys, c->cell_start, c->pos2, c->vel2, 0, tm.ncols, tm.tiles_per_col, c->tile_cells,
+                       c->pair_cap, c->col_lo, c->col_hi, mx, my, strength, c->fast_div ? 1 : 0);
+    LAUNCH_CHECK();
+    std::swap(c->vel, c->vel2);
     if (fuse_integrate) {
-        hipLaunchKernelGGL(k_force<true>, dim3(tm.nblocks), dim3(PAIR_THREADS), lds, c->stream, c->dc, c->pos, c->vel,
-                           c->rho, c->prs, c->idv, c->keys, c->cell_start, c->pos2, c->vel2, 0, tm.ncols,
-                           tm.tiles_per_col, c->tile_cells, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength);
-        LAUNCH_CHECK();
         std::swap(c->pos, c->pos2);
-        std::swap(c->vel, c->vel2);
         c->grid_valid = false;
-    } else {
-        hipLaunchKernelGGL(k_force<false>, dim3(tm.nblocks), dim3(PAIR_THREADS), lds, c->stream, c->dc, c->pos, c->vel,
-                           c->rho, c->prs, c->idv, c->keys, c->cell_start, c->pos2, c->vel2, 0, tm.ncols,
-                           tm.tiles_per_col, c->tile_cells, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength);
-        LAUNCH_CHECK();
-        std::swap(c->vel, c->vel2);
     }
     return SPHHIP_OK;
 }

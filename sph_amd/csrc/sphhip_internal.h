@@ -30,7 +30,7 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 2048 keys per workgroup
 constexpr int SORT_RADIX = 256;
 
 // ---- pair-kernel geometry -------------------------------------------------------------------
-constexpr int PAIR_THREADS = 256;
+// workgroup size of the pair kernels: 128 or 256 (runtime choice, SphCtx::pair_threads)
 constexpr int PAIR_MAX_TILE_CELLS = 64;  // cells of one column per workgroup (runtime <= this)
 
 struct PhaseTimer {
@@ -56,8 +56,10 @@ struct SphCtx {
     bool slice_valid = false;    // slots of [slice_lo, slice_hi) columns (at the last sort) = owned particles
     int slice_lo = 0, slice_hi = 0;
     int col_lo = 0, col_hi = 0;  // owned columns (default: all)
-    int tile_cells = 16;         // cells of a column per pair-kernel workgroup
-    int pair_cap = 1536;         // neighbour candidates staged in LDS per workgroup
+    int tile_cells = 12;         // cells of a column per pair-kernel workgroup
+    int pair_cap = 1024;
+    int pair_threads = 256;      // 128 or 256
+    bool fast_div = true;        // exact_div.h allowed (constants in its safe range; SPHHIP_FAST_DIV=0 disables)         // neighbour candidates staged in LDS per workgroup
 
     // state, SoA, all in the same (slot) order
     float2 *pos = nullptr, *vel = nullptr, *pos2 = nullptr, *vel2 = nullptr;
@@ -101,6 +103,7 @@ int sph_grid_build(SphCtx* c, bool carry_density);
 int sph_density_launch(SphCtx* c);
 int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate);
 int sph_integrate_launch(SphCtx* c);
+int sph_selftest_division(int device, unsigned long long* checked, unsigned long long* mismatches);
 int sph_unpack_aos(SphCtx* c, int n, int id_base);
 int sph_pack_aos(SphCtx* c, int n, uint32_t* d_ids_out);
 

@@ -7,7 +7,7 @@ import os
 from .params import SphDerived, SphParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsphhip.so")
+LIB_PATH = os.environ.get("SPHHIP_LIB") or os.path.join(_HERE, "libsphhip.so")  # override: kernel A/B builds only
 
 PH_NAMES = ["hash", "sort", "cells", "reorder", "density", "force", "integrate"]
 
@@ -43,6 +43,7 @@ SIGNATURES = {
     "sphhip_drop_ghosts": [_vp],
     "sphhip_append": [_vp, _vp, _ci],
     "sphhip_column_histogram": [_vp, _vp],
+    "sphhip_selftest_division": [_ci, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)],
     "sphhip_set_profiling": [_vp, _ci],
     "sphhip_get_phase_times": [_vp, _vp, _vp],
     "sphhip_reset_phase_times": [_vp],
