@@ -44,6 +44,11 @@ constexpr int PAIR_MAXC = 3 * (PAIR_MAX_TILE_CELLS + 2);  // candidate cells of 
 #define FORCE_HEAVY_UNROLL 4
 #endif
 constexpr int FORCE_QCAP = FORCE_Q + FORCE_SCAN_UNROLL + FORCE_HEAVY_UNROLL;  // pushes overshoot by < SCAN_UNROLL, reads by < HEAVY_UNROLL
+// After the three cells of every candidate row the LDS image holds PAIR_ROW_PAD sentinel records at
+// +inf: a lane may read up to PAIR_ROW_PAD records past the end of its range without a bounds test
+// (r2 = +inf fails the distance test); the sentinels inside its range fail the same way.
+constexpr int PAIR_ROW_PAD = 3;
+static_assert(FORCE_SCAN_UNROLL - 1 <= PAIR_ROW_PAD, "scan unroll reads past the range end");
 
 struct TileGeom {
     int col, cy0, cy1, ylo, yhi, own_lo, own_hi, ncells, total;
@@ -79,8 +84,13 @@ __device__ __forceinline__ int wg_excl_scan(int v, int* lds_wave, int& total) {
     return off + incl - v;
 }
 
-// Fills g, s_off[0..ncells] (LDS start of every candidate cell, row-major) and s_gs[0..ncells)
-// (global slot start of every candidate cell).  Returns false for an empty tile (uniform).
+// Fills g, s_off[0..ncells] (LDS start of every candidate cell, row-major, PAIR_ROW_PAD sentinel slots
+// after every third cell) and s_gs[0..ncells) (global slot start of every candidate cell).
+// Returns false for an empty tile (uniform).
+__device__ __forceinline__ int cand_count(const int* s_off, int cc) {  // real particles of candidate cell cc
+    return s_off[cc + 1] - s_off[cc] - ((cc % 3) == 2 ? PAIR_ROW_PAD : 0);
+}
+
 template <int THREADS>
 __device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __restrict__ cell_start, int col, int trow,
                                            int tile_cells, TileGeom& g, int* s_off, int* s_gs, int* s_wave) {
@@ -104,7 +114,8 @@ __device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __rest
             cnt = cell_start[key + 1] - g0;
         }
     }
-    int ex = wg_excl_scan<THREADS>(cnt, s_wave, g.total);
+    int padded = cnt + ((t < g.ncells && (t % 3) == 2) ? PAIR_ROW_PAD : 0);
+    int ex = wg_excl_scan<THREADS>(padded, s_wave, g.total);
     if (t < g.ncells) {
         s_off[t] = ex;
         s_gs[t] = g0;
@@ -148,9 +159,12 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
     if (use_lds) {
         // 16 lanes per candidate cell, 16 cells per pass
         for (int cc = threadIdx.x >> 4; cc < g.ncells; cc += THREADS / 16) {
-            int o = s_off[cc], n = s_off[cc + 1] - o, gs = s_gs[cc];
+            int o = s_off[cc], n = cand_count(s_off, cc), gs = s_gs[cc];
             for (int k = threadIdx.x & 15; k < n; k += 16) s_pos[o + k] = pos[gs + k];
         }
+        for (int t = threadIdx.x; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS)
+            s_pos[s_off[3 * (t / PAIR_ROW_PAD) + 3] - PAIR_ROW_PAD + (t % PAIR_ROW_PAD)] =
+                make_float2(__builtin_inff(), __builtin_inff());
         __syncthreads();
     }
     for (int s = g.own_lo + (int)threadIdx.x; s < g.own_hi; s += THREADS) {
@@ -160,11 +174,11 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
         float dens = 0.0f;
         int cnt = 0;
         if (use_lds) {
-            const int lo = s_off[3 * r0], hi = s_off[3 * r1 + 3];
-            for (int j = lo; j < hi; j++) density_acc(c, pi, s_pos[j], dens, cnt);
+            const int lo = s_off[3 * r0], hi = s_off[3 * r1 + 3] - PAIR_ROW_PAD;
+            for (int j = lo; j < hi; j++) density_acc(c, pi, s_pos[j], dens, cnt);  // sentinels: r2 = inf
         } else {
             for (int cc = 3 * r0; cc < 3 * r1 + 3; cc++) {
-                int gs = s_gs[cc], n = s_off[cc + 1] - s_off[cc];
+                int gs = s_gs[cc], n = cand_count(s_off, cc);
                 for (int j = gs; j < gs + n; j++) density_acc(c, pi, pos[j], dens, cnt);
             }
         }
@@ -181,6 +195,9 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
 // the U pairs so that their long dependent chains (sqrt, four divisions) interleave in the
 // instruction stream.  (rx, ry) = p_i - p_j.  Every operation is the reference's, in its order.
 // ---------------------------------------------------------------------------------------------
+// (*) The reference's `r_len > h` guards (sph.cpp:16,24) are dead here: a pair is evaluated only if
+// r2 < RN(h*h), hence r2 <= h*h exactly or r2 is the float just below RN(h*h) <= h*h(1+2^-24), and the
+// correctly rounded sqrt of either is <= h.  (A NaN r_len fails `>` as well.)
 // FAST: divisions through exact_div.h (operands checked to be in the safe range when the tile was
 // staged); otherwise hipcc's generic correctly rounded `/`.  Same results bit for bit.
 template <int U, bool FAST>
@@ -209,8 +226,8 @@ __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx
             pt[u] = 0.5f * sph_div_with_rcp(pres_i + aj[u].w, aj[u].z, yd[u]);  // sph.cpp:69
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            float lap = (r_len[u] > c.h) ? 0.0f : c.visc_lap * (c.h - r_len[u]);  // sph.cpp:23-26
-            visc[u] = sph_div_with_rcp(c.visc_mass * lap, aj[u].z, yd[u]);         // sph.cpp:72
+            float lap = c.visc_lap * (c.h - r_len[u]);                      // sph.cpp:23-26, see note (*)
+            visc[u] = sph_div_with_rcp(c.visc_mass * lap, aj[u].z, yd[u]);  // sph.cpp:72
         }
     } else {
 #pragma unroll
@@ -224,8 +241,8 @@ __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx
         for (int u = 0; u < U; u++) pt[u] = (pres_i + aj[u].w) / (2.0f * aj[u].z);  // sph.cpp:69
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            float lap = (r_len[u] > c.h) ? 0.0f : c.visc_lap * (c.h - r_len[u]);  // sph.cpp:23-26
-            visc[u] = c.visc_mass * lap / aj[u].z;                                 // sph.cpp:72
+            float lap = c.visc_lap * (c.h - r_len[u]);  // sph.cpp:23-26, see note (*)
+            visc[u] = c.visc_mass * lap / aj[u].z;      // sph.cpp:72
         }
     }
 #pragma unroll
@@ -241,7 +258,7 @@ __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx
     for (int u = 0; u < U; u++) {
         // spiky gradient guard, sph.cpp:16.  `r_len < 1e-6` there is a double compare: true for
         // r_len <= 1e-6f (the float just below 1e-6), false from the next float up.
-        bool zero_grad = (r_len[u] > c.h) || (r_len[u] <= 1e-6f);
+        bool zero_grad = r_len[u] <= 1e-6f;  // note (*)
         float gx = zero_grad ? 0.0f : gcoeff[u] * rx[u];
         float gy = zero_grad ? 0.0f : gcoeff[u] * ry[u];
         float pfx = c.neg_mass * pt[u] * gx;  // sph.cpp:70
@@ -325,6 +342,79 @@ __device__ __forceinline__ void integrate_one(const DevConsts& c, float2& p, flo
 // Tiles whose column is outside [own_lo_col, own_hi_col) only pass their particles through
 // (ghost columns of a slab).
 // ---------------------------------------------------------------------------------------------
+// The per-particle neighbour sum of the force pass over the LDS image, for the whole wave at once.
+// Rounds: (1) every lane scans its candidate range until it has queued FORCE_Q in-range neighbours
+// (cheap distance test only; indices go to a per-lane LDS queue in scan order), (2) all lanes
+// evaluate their queued pairs together, FORCE_HEAVY_UNROLL independent pairs in flight per lane.
+// The expensive pair arithmetic thus runs with (nearly) all lanes active instead of being predicated
+// on a per-candidate distance test, and it stays in the canonical order.
+//
+// FAST (tile operands proven safe for exact_div.h): the particle itself is NOT filtered out of the
+// scan -- its term is exactly +0 (r_len = 0: gradient and LJ are zeroed by their guards, relVel is
+// +0, the pressure factor is finite because rho_i is in the safe range) and force + 0 == force --
+// and the queue tail is padded with the particle itself, so the accumulation needs no predicate.
+// !FAST keeps the reference's `j == i` test (sph.cpp:63) and a predicated accumulation.
+template <int THREADS, bool FAST>
+__device__ __forceinline__ void force_rounds(const DevConsts& c, const float2* s_pos, const float4* s_aux,
+                                             unsigned short* s_q, int j, int hi, int self, float2 pi, float2 vi,
+                                             float pres_i, float& fx, float& fy) {
+    const int tid = threadIdx.x;
+    while (__any(j < hi)) {
+        int qn = 0;
+        while (__any((j < hi) && (qn < FORCE_Q))) {
+            if ((j < hi) && (qn < FORCE_Q)) {
+                float2 q[FORCE_SCAN_UNROLL];
+#pragma unroll
+                for (int u = 0; u < FORCE_SCAN_UNROLL; u++) q[u] = s_pos[j + u];  // may run into the row sentinels
+#pragma unroll
+                for (int u = 0; u < FORCE_SCAN_UNROLL; u++) {
+                    float rx = pi.x - q[u].x, ry = pi.y - q[u].y;
+                    float r2 = rx * rx + ry * ry;
+                    bool in = !(r2 >= c.h2);  // sph.cpp:66
+                    if (!FAST) in = in && (j + u != self);  // sph.cpp:63
+                    // branch-free push: the slot is rewritten until a candidate is accepted
+                    s_q[qn * THREADS + tid] = (unsigned short)(j + u);
+                    qn += in ? 1 : 0;
+                }
+                j += FORCE_SCAN_UNROLL;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FORCE_HEAVY_UNROLL - 1; u++) s_q[(qn + u) * THREADS + tid] = (unsigned short)self;
+        for (int t = 0; __any(t < qn); t += FORCE_HEAVY_UNROLL) {
+            int jj[FORCE_HEAVY_UNROLL];
+            float tx[FORCE_HEAVY_UNROLL], ty[FORCE_HEAVY_UNROLL];
+            float rx[FORCE_HEAVY_UNROLL], ry[FORCE_HEAVY_UNROLL], r2[FORCE_HEAVY_UNROLL];
+            float4 aj[FORCE_HEAVY_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+                int e = s_q[(t + u) * THREADS + tid];
+                jj[u] = (t < qn) ? e : self;  // a lane whose queue is exhausted re-evaluates itself
+            }
+#pragma unroll
+            for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+                float2 q = s_pos[jj[u]];
+                aj[u] = s_aux[jj[u]];
+                rx[u] = pi.x - q.x;
+                ry[u] = pi.y - q.y;
+                r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
+            }
+            force_terms<FORCE_HEAVY_UNROLL, FAST>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, tx, ty);
+            // same order as the sequential sum: force += term(t); force += term(t+1); ...
+#pragma unroll
+            for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+                if (FAST) {
+                    fx += tx[u];
+                    fy += ty[u];
+                } else {
+                    fx = (t + u < qn) ? fx + tx[u] : fx;
+                    fy = (t + u < qn) ? fy + ty[u] : fy;
+                }
+            }
+        }
+    }
+}
+
 #ifndef FORCE_WAVES_MAX
 #define FORCE_WAVES_MAX 4
 #endif
@@ -371,7 +461,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
     if (use_lds) {
         int unsafe = allow_fast ? 0 : 1;
         for (int cc = threadIdx.x >> 4; cc < g.ncells; cc += THREADS / 16) {
-            int o = s_off[cc], n = s_off[cc + 1] - o, gs = s_gs[cc];
+            int o = s_off[cc], n = cand_count(s_off, cc), gs = s_gs[cc];
             for (int k = threadIdx.x & 15; k < n; k += 16) {
                 int j = gs + k;
                 float2 q = pos[j];
@@ -385,6 +475,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
                 s_pos[o + k] = q;
                 s_aux[o + k] = make_float4(w.x, w.y, dj, pj);
             }
+        }
+        for (int t = threadIdx.x; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS) {
+            int idx = s_off[3 * (t / PAIR_ROW_PAD) + 3] - PAIR_ROW_PAD + (t % PAIR_ROW_PAD);
+            s_pos[idx] = make_float2(inf, inf);
+            s_aux[idx] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
         }
         fast = !__syncthreads_or(unsafe);
     }
@@ -412,71 +507,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
         }
         float fx = 0.0f, fy = 0.0f;
         if (use_lds) {
-            int j = 0, hi = 0, self = -1;
+            int j = 0, hi = 0, self = 0;
             if (have && valid) {  // sph.cpp:59: invalid particles get no force
                 j = s_off[3 * r0];
-                hi = s_off[3 * r1 + 3];
+                hi = s_off[3 * r1 + 3] - PAIR_ROW_PAD;
                 self = s_off[self_cell] + (s - s_gs[self_cell]);
             }
-            // Rounds: (1) every lane scans its candidates until it has gathered FORCE_Q in-range
-            // neighbours (cheap test, indices queued in LDS in scan order); (2) all lanes evaluate
-            // their queued pairs together.  The expensive pair arithmetic then runs with (nearly)
-            // all lanes active instead of being predicated on a per-candidate distance test.
-            while (__any(j < hi)) {
-                int qn = 0;
-                while (__any((j < hi) && (qn < FORCE_Q))) {
-                    if ((j < hi) && (qn < FORCE_Q)) {
-                        float2 q[FORCE_SCAN_UNROLL];
-#pragma unroll
-                        for (int u = 0; u < FORCE_SCAN_UNROLL; u++) q[u] = s_pos[min(j + u, hi - 1)];
-#pragma unroll
-                        for (int u = 0; u < FORCE_SCAN_UNROLL; u++) {
-                            int jj = j + u;
-                            float rx = pi.x - q[u].x, ry = pi.y - q[u].y;
-                            float r2 = rx * rx + ry * ry;
-                            bool in = (jj < hi) && !(r2 >= c.h2) && (jj != self);  // sph.cpp:63,66
-                            // branch-free push: the slot is rewritten until a candidate is accepted
-                            s_q[qn * THREADS + threadIdx.x] = (unsigned short)jj;
-                            qn += in ? 1 : 0;
-                        }
-                        j += FORCE_SCAN_UNROLL;
-                    }
-                }
-                // FORCE_HEAVY_UNROLL independent pair evaluations in flight per lane (no branches:
-                // a lane past its queue end evaluates a harmless dummy candidate and discards it)
-                for (int t = 0; __any(t < qn); t += FORCE_HEAVY_UNROLL) {
-                    int jj[FORCE_HEAVY_UNROLL];
-                    float tx[FORCE_HEAVY_UNROLL], ty[FORCE_HEAVY_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
-                        int e = s_q[(t + u) * THREADS + threadIdx.x];
-                        jj[u] = (t + u < qn) ? e : 0;
-                    }
-                    float rx[FORCE_HEAVY_UNROLL], ry[FORCE_HEAVY_UNROLL], r2[FORCE_HEAVY_UNROLL];
-                    float4 aj[FORCE_HEAVY_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
-                        float2 q = s_pos[jj[u]];
-                        aj[u] = s_aux[jj[u]];
-                        rx[u] = pi.x - q.x;
-                        ry[u] = pi.y - q.y;
-                        r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
-                    }
-                    if (fast)  // uniform over the workgroup
-                        force_terms<FORCE_HEAVY_UNROLL, true>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, tx, ty);
-                    else
-                        force_terms<FORCE_HEAVY_UNROLL, false>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, tx, ty);
-                    // same order as the sequential sum: force += term(t); force += term(t+1); ...
-#pragma unroll
-                    for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
-                        fx = (t + u < qn) ? fx + tx[u] : fx;
-                        fy = (t + u < qn) ? fy + ty[u] : fy;
-                    }
-                }
-            }
+            if (fast)
+                force_rounds<THREADS, true>(c, s_pos, s_aux, s_q, j, hi, self, pi, vi, pres_i, fx, fy);
+            else
+                force_rounds<THREADS, false>(c, s_pos, s_aux, s_q, j, hi, self, pi, vi, pres_i, fx, fy);
         } else if (have && valid) {
             for (int cc = 3 * r0; cc < 3 * r1 + 3; cc++) {
-                int gs = s_gs[cc], n = s_off[cc + 1] - s_off[cc];
+                int gs = s_gs[cc], n = cand_count(s_off, cc);
                 for (int j = gs; j < gs + n; j++) {
                     float2 q = pos[j];
                     if (idv[j] & SPH_INVALID_BIT) q = make_float2(inf, inf);
