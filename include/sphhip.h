@@ -101,6 +101,9 @@ int sphhip_create(const SphParams* p, int n_max, int device, SphCtx** out);
 int sphhip_destroy(SphCtx* ctx);
 /* Run on a caller-owned HIP stream (hipStream_t as void*; NULL => the context's own stream). */
 int sphhip_set_stream(SphCtx* ctx, void* hip_stream);
+/* Run on the device's default (null) stream, e.g. to be ordered with a framework that works on
+ * it (the context's own stream is non-blocking and does not synchronise with the null stream). */
+int sphhip_use_default_stream(SphCtx* ctx);
 int sphhip_get_stream(SphCtx* ctx, void** hip_stream);
 int sphhip_synchronize(SphCtx* ctx);
 const char* sphhip_last_error(void);
@@ -176,6 +179,19 @@ int sphhip_set_owned_columns(SphCtx* ctx, int col_lo, int col_hi);
 int sphhip_pack_halo(SphCtx* ctx, int send_hi_left, int send_lo_right,
                      void* d_left, int cap_left, int* n_left,
                      void* d_right, int cap_right, int* n_right);
+/* The same split without a host synchronisation, for a fixed-size exchange: d_msg_left /
+ * d_msg_right are device buffers of (cap + 1) 20-byte records whose record 0 is a header (word 0 =
+ * number of records that follow); either may be NULL (no neighbour on that side).  The messages
+ * can be sent as they are, stream-ordered behind this call.  Must be followed by
+ * sphhip_finish_exchange before any other call on the context. */
+int sphhip_pack_halo_async(SphCtx* ctx, int send_hi_left, int send_lo_right, void* d_msg_left, void* d_msg_right,
+                           int cap);
+/* Completes the exchange with ONE stream synchronisation: reads back the kept count and the
+ * headers of the two sent and the two received messages (counts5 = {sent left, sent right,
+ * received left, received right, kept}; may be NULL), then appends the received records.
+ * Fails with SPHHIP_ECAPACITY if any message overflowed `cap`. */
+int sphhip_finish_exchange(SphCtx* ctx, const void* d_msg_left, const void* d_msg_right, const void* d_recv_left,
+                           const void* d_recv_right, int cap, int* counts5);
 /* Drops every particle whose column is outside [col_lo, col_hi); sends nothing. */
 int sphhip_keep_columns(SphCtx* ctx, int col_lo, int col_hi);
 /* Drops the ghost copies left over from the last step on a slab (particles that were outside the

@@ -240,6 +240,13 @@ extern "C" int sphhip_set_stream(SphCtx* c, void* s) {
     return SPHHIP_OK;
 }
 
+extern "C" int sphhip_use_default_stream(SphCtx* c) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = nullptr;  // the legacy default (null) stream
+    return SPHHIP_OK;
+}
+
 extern "C" int sphhip_get_stream(SphCtx* c, void** s) {
     if (!c || !s) return fail(SPHHIP_EINVAL, "null argument");
     *s = (void*)c->stream;
@@ -368,6 +375,7 @@ extern "C" int sphhip_count(SphCtx* c, int* n) {
     do {                                                                         \
         if (!(c)) return fail(SPHHIP_EINVAL, "null context");                    \
         if (!(c)->have_state) return fail(SPHHIP_ESTATE, "no particles uploaded"); \
+        if ((c)->n_pending) return fail(SPHHIP_ESTATE, "exchange in flight: call sphhip_finish_exchange first"); \
         HIP_TRY(hipSetDevice((c)->device));                                      \
     } while (0)
 
@@ -510,7 +518,8 @@ __global__ __launch_bounds__(256) void k_split(DevConsts c, int n, const float2*
                                                 HaloRec* __restrict__ right, int cap_right,
                                                 float2* __restrict__ pos_o, float2* __restrict__ vel_o,
                                                 float* __restrict__ rho_o, float* __restrict__ prs_o,
-                                                uint32_t* __restrict__ idv_o, int* __restrict__ counters,
+                                                uint32_t* __restrict__ idv_o, int* __restrict__ cnt_left,
+                                                int* __restrict__ cnt_right, int* __restrict__ cnt_keep,
                                                 const int* __restrict__ cell_start, int slice_lo_cell,
                                                 int slice_hi_cell) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -524,15 +533,15 @@ __global__ __launch_bounds__(256) void k_split(DevConsts c, int n, const float2*
     int col = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
     HaloRec r = {p.x, p.y, v.x, v.y, w};
     if (col < send_hi_left) {
-        int k = atomicAdd(&counters[0], 1);
+        int k = atomicAdd(cnt_left, 1);
         if (k < cap_left) left[k] = r;
     }
     if (col >= send_lo_right) {
-        int k = atomicAdd(&counters[1], 1);
+        int k = atomicAdd(cnt_right, 1);
         if (k < cap_right) right[k] = r;
     }
     if (col >= keep_lo && col < keep_hi) {
-        int k = atomicAdd(&counters[2], 1);
+        int k = atomicAdd(cnt_keep, 1);
         pos_o[k] = p;
         vel_o[k] = v;
         rho_o[k] = rho[i];
@@ -541,38 +550,98 @@ __global__ __launch_bounds__(256) void k_split(DevConsts c, int n, const float2*
     }
 }
 
-static int split_impl(SphCtx* c, int send_hi_left, int send_lo_right, int keep_lo, int keep_hi, void* d_left,
-                      int cap_left, int* n_left, void* d_right, int cap_right, int* n_right) {
-    if (!n_left || !n_right) return fail(SPHHIP_EINVAL, "null argument");
-    if ((cap_left > 0 && !d_left) || (cap_right > 0 && !d_right)) return fail(SPHHIP_EINVAL, "null buffer");
+// Enqueues the split.  Counters: cnt_left / cnt_right may live in the message headers (fixed-size
+// exchange) or in c->counters[0..1]; the kept count always goes to c->counters[2].
+static int split_enqueue(SphCtx* c, int send_hi_left, int send_lo_right, int keep_lo, int keep_hi, HaloRec* d_left,
+                         int cap_left, int* cnt_left, HaloRec* d_right, int cap_right, int* cnt_right) {
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(int) * 4, c->stream));
+    if (cnt_left != c->counters) HIP_TRY(hipMemsetAsync(cnt_left, 0, sizeof(HaloRec), c->stream));
+    if (cnt_right != c->counters + 1) HIP_TRY(hipMemsetAsync(cnt_right, 0, sizeof(HaloRec), c->stream));
     const int n = c->n;
     if (n > 0) {
         hipLaunchKernelGGL(k_split, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dc, n, c->pos, c->vel, c->rho,
-                           c->prs, c->idv, send_hi_left, send_lo_right, keep_lo, keep_hi, (HaloRec*)d_left,
-                           cap_left, (HaloRec*)d_right, cap_right, c->pos2, c->vel2, c->rho2, c->prs2, c->idv2,
-                           c->counters, c->slice_valid ? c->cell_start : nullptr, c->slice_lo * c->dc.ny,
+                           c->prs, c->idv, send_hi_left, send_lo_right, keep_lo, keep_hi, d_left, cap_left, d_right,
+                           cap_right, c->pos2, c->vel2, c->rho2, c->prs2, c->idv2, cnt_left, cnt_right,
+                           c->counters + 2, c->slice_valid ? c->cell_start : nullptr, c->slice_lo * c->dc.ny,
                            c->slice_hi * c->dc.ny);
         LAUNCH_CHECK();
     }
-    int h[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(h, c->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (h[0] > cap_left || h[1] > cap_right) {
-        return fail(SPHHIP_ECAPACITY, "sphhip_pack_halo: halo buffer too small");
-    }
-    *n_left = h[0];
-    *n_right = h[1];
     std::swap(c->pos, c->pos2);
     std::swap(c->vel, c->vel2);
     std::swap(c->rho, c->rho2);
     std::swap(c->prs, c->prs2);
     std::swap(c->idv, c->idv2);
-    c->n = h[2];
     c->grid_valid = false;
     c->counts_valid = false;
     c->slice_valid = false;
+    c->n_pending = true;  // c->n is stale until the kept count has been read back
     return SPHHIP_OK;
+}
+
+static int split_impl(SphCtx* c, int send_hi_left, int send_lo_right, int keep_lo, int keep_hi, void* d_left,
+                      int cap_left, int* n_left, void* d_right, int cap_right, int* n_right) {
+    if (!n_left || !n_right) return fail(SPHHIP_EINVAL, "null argument");
+    if ((cap_left > 0 && !d_left) || (cap_right > 0 && !d_right)) return fail(SPHHIP_EINVAL, "null buffer");
+    int rc = split_enqueue(c, send_hi_left, send_lo_right, keep_lo, keep_hi, (HaloRec*)d_left, cap_left, c->counters,
+                           (HaloRec*)d_right, cap_right, c->counters + 1);
+    if (rc) return rc;
+    int h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, c->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n = h[2];
+    c->n_pending = false;
+    if (h[0] > cap_left || h[1] > cap_right) return fail(SPHHIP_ECAPACITY, "sphhip_pack_halo: halo buffer too small");
+    *n_left = h[0];
+    *n_right = h[1];
+    return SPHHIP_OK;
+}
+
+// ---- fixed-size exchange: one host synchronisation per step --------------------------------
+__global__ void k_gather_counts(const int* a, const int* b, const int* c2, const int* d, const int* keep, int* out) {
+    if (threadIdx.x == 0) {
+        out[0] = a ? a[0] : 0;
+        out[1] = b ? b[0] : 0;
+        out[2] = c2 ? c2[0] : 0;
+        out[3] = d ? d[0] : 0;
+        out[4] = keep[0];
+    }
+}
+
+extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_right, void* d_msg_left,
+                                      void* d_msg_right, int cap) {
+    NEED_STATE(c);
+    if (cap < 0) return fail(SPHHIP_EINVAL, "sphhip_pack_halo_async: negative capacity");
+    HaloRec* l = (HaloRec*)d_msg_left;
+    HaloRec* r = (HaloRec*)d_msg_right;
+    // record 0 of a message is its header (word 0 = record count); records follow from row 1
+    return split_enqueue(c, l ? send_hi_left : -1, r ? send_lo_right : 0x7fffffff, c->col_lo - SPHHIP_HALO_COLS,
+                         c->col_hi + SPHHIP_HALO_COLS, l ? l + 1 : nullptr, l ? cap : 0, l ? (int*)l : c->counters,
+                         r ? r + 1 : nullptr, r ? cap : 0, r ? (int*)r : c->counters + 1);
+}
+
+static int append_records(SphCtx* c, const void* d_records, int n);
+
+extern "C" int sphhip_finish_exchange(SphCtx* c, const void* d_msg_left, const void* d_msg_right,
+                                      const void* d_recv_left, const void* d_recv_right, int cap, int* counts5) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->n_pending) return fail(SPHHIP_ESTATE, "sphhip_finish_exchange: no exchange in flight");
+    hipLaunchKernelGGL(k_gather_counts, dim3(1), dim3(64), 0, c->stream, (const int*)d_msg_left, (const int*)d_msg_right,
+                       (const int*)d_recv_left, (const int*)d_recv_right, c->counters + 2, c->counters + 8);
+    LAUNCH_CHECK();
+    int h[5] = {0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, c->counters + 8, sizeof(int) * 5, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n = h[4];
+    c->n_pending = false;
+    if (counts5) memcpy(counts5, h, sizeof h);
+    if (h[0] > cap || h[1] > cap) return fail(SPHHIP_ECAPACITY, "sphhip_finish_exchange: halo message buffer too small");
+    if (h[2] < 0 || h[3] < 0 || h[2] > cap || h[3] > cap)
+        return fail(SPHHIP_ECAPACITY, "sphhip_finish_exchange: received halo message exceeds the buffer");
+    int rc = SPHHIP_OK;
+    if (d_recv_left && h[2]) rc = append_records(c, (const HaloRec*)d_recv_left + 1, h[2]);
+    if (!rc && d_recv_right && h[3]) rc = append_records(c, (const HaloRec*)d_recv_right + 1, h[3]);
+    return rc;
 }
 
 extern "C" int sphhip_pack_halo(SphCtx* c, int send_hi_left, int send_lo_right, void* d_left, int cap_left,
@@ -615,7 +684,12 @@ __global__ __launch_bounds__(256) void k_append(const HaloRec* __restrict__ rec,
 extern "C" int sphhip_append(SphCtx* c, const void* d_records, int n) {
     if (!c) return fail(SPHHIP_EINVAL, "null context");
     if (n < 0 || (n > 0 && !d_records)) return fail(SPHHIP_EINVAL, "sphhip_append: bad argument");
+    if (c->n_pending) return fail(SPHHIP_ESTATE, "sphhip_append: exchange in flight (call sphhip_finish_exchange)");
     HIP_TRY(hipSetDevice(c->device));
+    return append_records(c, d_records, n);
+}
+
+static int append_records(SphCtx* c, const void* d_records, int n) {
     if (c->slice_valid && c->have_state) {  // stale ghosts of the last step must not mix with new records
         int rc = sphhip_drop_ghosts(c);
         if (rc) return rc;

@@ -53,6 +53,7 @@ struct SphCtx {
     bool have_state = false;
     bool grid_valid = false;
     bool counts_valid = false;
+    bool n_pending = false;      // an asynchronous split is in flight: n is not known on the host yet
     bool slice_valid = false;    // slots of [slice_lo, slice_hi) columns (at the last sort) = owned particles
     int slice_lo = 0, slice_hi = 0;
     int col_lo = 0, col_hi = 0;  // owned columns (default: all)

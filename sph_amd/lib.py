@@ -23,6 +23,7 @@ SIGNATURES = {
     "sphhip_create": [ctypes.POINTER(SphParams), _ci, _ci, ctypes.POINTER(_vp)],
     "sphhip_destroy": [_vp],
     "sphhip_set_stream": [_vp, _vp],
+    "sphhip_use_default_stream": [_vp],
     "sphhip_get_stream": [_vp, ctypes.POINTER(_vp)],
     "sphhip_synchronize": [_vp],
     "sphhip_set_tuning": [_vp, _ci, _ci],
@@ -39,6 +40,8 @@ SIGNATURES = {
     "sphhip_get_neighbor_counts": [_vp, _vp, _ci],
     "sphhip_set_owned_columns": [_vp, _ci, _ci],
     "sphhip_pack_halo": [_vp, _ci, _ci, _vp, _ci, _pi, _vp, _ci, _pi],
+    "sphhip_pack_halo_async": [_vp, _ci, _ci, _vp, _vp, _ci],
+    "sphhip_finish_exchange": [_vp, _vp, _vp, _vp, _vp, _ci, _pi],
     "sphhip_keep_columns": [_vp, _ci, _ci],
     "sphhip_drop_ghosts": [_vp],
     "sphhip_append": [_vp, _vp, _ci],

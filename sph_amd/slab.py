@@ -65,7 +65,9 @@ def balanced_bounds(hist, world, min_width=MIN_SLAB_COLS, prev=None):
 
 
 class HipSlabBackend:
-    """The product backend: libsphhip.so on one GPU, exchange buffers as torch CUDA tensors."""
+    """The product backend: libsphhip.so on one GPU, exchange messages as torch CUDA tensors.
+    A message is an int32 tensor of (cap + 1) x 5 words: row 0 is the header (word 0 = number of
+    20-byte records that follow), so it can be sent at its fixed size without a count round trip."""
 
     def __init__(self, params, n_max, device, halo_cap):
         self.device = torch.device("cuda", device)
@@ -73,29 +75,33 @@ class HipSlabBackend:
         self.drv = self.solver.drv
         # run the library on torch's current stream so that RCCL ops and kernels are ordered
         self.solver.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
-        self.halo_cap = int(halo_cap)
-        self.send_l = torch.empty((self.halo_cap, 5), dtype=torch.int32, device=self.device)
-        self.send_r = torch.empty((self.halo_cap, 5), dtype=torch.int32, device=self.device)
-
-    def new_buffer(self, n):
-        return torch.empty((n, 5), dtype=torch.int32, device=self.device)
+        self.cap = int(halo_cap)
+        mk = lambda: torch.zeros((self.cap + 1, 5), dtype=torch.int32, device=self.device)  # noqa: E731
+        self.send_l, self.send_r, self.recv_l, self.recv_r = mk(), mk(), mk(), mk()
 
     def set_owned(self, lo, hi):
         self.solver.set_owned_columns(lo, hi)
 
-    def pack(self, send_hi_left, send_lo_right):
-        nl, nr = self.solver.pack_halo(send_hi_left, send_lo_right, self.send_l.data_ptr(), self.halo_cap,
-                                       self.send_r.data_ptr(), self.halo_cap)
-        return self.send_l[:nl], self.send_r[:nr]
+    def pack(self, send_hi_left, send_lo_right, has_left, has_right):
+        """Enqueues the split; returns the two outgoing messages (None where there is no neighbour)."""
+        self.solver.pack_halo_async(send_hi_left, send_lo_right, self.send_l.data_ptr() if has_left else None,
+                                    self.send_r.data_ptr() if has_right else None, self.cap)
+        return (self.send_l if has_left else None), (self.send_r if has_right else None)
 
-    def append(self, rec):
-        if rec.shape[0]:
-            assert rec.is_contiguous()
-            self.solver.append(rec.data_ptr(), rec.shape[0])
+    def recv_buffers(self):
+        return self.recv_l, self.recv_r
+
+    def finish(self, has_left, has_right):
+        """One host sync: read all counts, append what was received."""
+        return self.solver.finish_exchange(self.send_l.data_ptr() if has_left else None,
+                                           self.send_r.data_ptr() if has_right else None,
+                                           self.recv_l.data_ptr() if has_left else None,
+                                           self.recv_r.data_ptr() if has_right else None, self.cap)
 
     def append_host(self, rec_np):
         t = torch.from_numpy(np.ascontiguousarray(rec_np).view(np.int32).reshape(-1, 5)).to(self.device)
-        self.append(t)
+        if t.shape[0]:
+            self.solver.append(t.data_ptr(), t.shape[0])
         torch.cuda.synchronize(self.device)
 
     def step(self, mouse, strength):
@@ -151,60 +157,45 @@ class SlabSolver:
         return self.bounds
 
     # -- halo exchange + migration ------------------------------------------------------------
-    def _exchange(self, left, right):
-        r, w = self.rank, self.world
-        out_dev = left.device
-        if self.stage_cpu and out_dev.type != "cpu":
-            left, right = left.cpu(), right.cpu()
-        dev = left.device
-        has_l, has_r = r > 0, r < w - 1
-        cnt_out_l = torch.tensor([left.shape[0]], dtype=torch.int64, device=dev)
-        cnt_out_r = torch.tensor([right.shape[0]], dtype=torch.int64, device=dev)
-        cnt_in_l = torch.zeros(1, dtype=torch.int64, device=dev)
-        cnt_in_r = torch.zeros(1, dtype=torch.int64, device=dev)
+    def _exchange(self, left, right, recv_l, recv_r):
+        """One fixed-size message per direction (header + records); no count round trip."""
+        r = self.rank
+        stage = self.stage_cpu and (left if left is not None else right) is not None and \
+            (left if left is not None else right).device.type != "cpu"
+        if stage:
+            out_l, out_r = recv_l, recv_r
+            left = left.cpu() if left is not None else None
+            right = right.cpu() if right is not None else None
+            recv_l = torch.empty(recv_l.shape, dtype=recv_l.dtype) if left is not None else None
+            recv_r = torch.empty(recv_r.shape, dtype=recv_r.dtype) if right is not None else None
         ops = []
-        if has_l:
-            ops += [dist.P2POp(dist.isend, cnt_out_l, self._peer(r - 1), self.group),
-                    dist.P2POp(dist.irecv, cnt_in_l, self._peer(r - 1), self.group)]
-        if has_r:
-            ops += [dist.P2POp(dist.isend, cnt_out_r, self._peer(r + 1), self.group),
-                    dist.P2POp(dist.irecv, cnt_in_r, self._peer(r + 1), self.group)]
+        if left is not None:
+            ops += [dist.P2POp(dist.isend, left, self._peer(r - 1), self.group),
+                    dist.P2POp(dist.irecv, recv_l, self._peer(r - 1), self.group)]
+        if right is not None:
+            ops += [dist.P2POp(dist.isend, right, self._peer(r + 1), self.group),
+                    dist.P2POp(dist.irecv, recv_r, self._peer(r + 1), self.group)]
         if ops:
             for q in dist.batch_isend_irecv(ops):
                 q.wait()
-        n_in_l, n_in_r = int(cnt_in_l.item()), int(cnt_in_r.item())
-        if dev == out_dev:
-            recv_l, recv_r = self.backend.new_buffer(n_in_l), self.backend.new_buffer(n_in_r)
-        else:
-            recv_l = torch.empty((n_in_l, 5), dtype=torch.int32)
-            recv_r = torch.empty((n_in_r, 5), dtype=torch.int32)
-        ops = []
-        if has_l and left.shape[0]:
-            ops.append(dist.P2POp(dist.isend, left, self._peer(r - 1), self.group))
-        if has_l and n_in_l:
-            ops.append(dist.P2POp(dist.irecv, recv_l, self._peer(r - 1), self.group))
-        if has_r and right.shape[0]:
-            ops.append(dist.P2POp(dist.isend, right, self._peer(r + 1), self.group))
-        if has_r and n_in_r:
-            ops.append(dist.P2POp(dist.irecv, recv_r, self._peer(r + 1), self.group))
-        if ops:
-            for q in dist.batch_isend_irecv(ops):
-                q.wait()
-        if dev != out_dev:
-            recv_l, recv_r = recv_l.to(out_dev), recv_r.to(out_dev)
-        return recv_l, recv_r
+        if stage:
+            if left is not None:
+                out_l.copy_(recv_l)
+            if right is not None:
+                out_r.copy_(recv_r)
 
     def _peer(self, group_rank):
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
 
     def step(self, nsteps=1, mouse=(0.0, 0.0), strength=0.0):
+        has_l, has_r = self.rank > 0, self.rank < self.world - 1
         for _ in range(nsteps):
-            send_hi_left = self.c0 + HALO_COLS if self.rank > 0 else -1
-            send_lo_right = self.c1 - HALO_COLS if self.rank < self.world - 1 else BIG
-            left, right = self.backend.pack(send_hi_left, send_lo_right)
-            recv_l, recv_r = self._exchange(left, right)
-            self.backend.append(recv_l)
-            self.backend.append(recv_r)
+            send_hi_left = self.c0 + HALO_COLS if has_l else -1
+            send_lo_right = self.c1 - HALO_COLS if has_r else BIG
+            left, right = self.backend.pack(send_hi_left, send_lo_right, has_l, has_r)
+            recv_l, recv_r = self.backend.recv_buffers()
+            self._exchange(left, right, recv_l, recv_r)
+            self.backend.finish(has_l, has_r)
             self.backend.step(mouse, strength)
 
     # -- state --------------------------------------------------------------------------------
@@ -261,7 +252,7 @@ def make_hip_slab(params, particles_or_fn, device, group=None, hist=None):
         hist = np.bincount(col, minlength=drv.nx)
     bounds = balanced_bounds(hist, world)
     per = int(np.max([np.sum(hist[bounds[g]:bounds[g + 1]]) for g in range(world)]))
-    halo_cap = int(max(4 * HALO_COLS * np.max(hist), 4096))
+    halo_cap = int(max(2.5 * HALO_COLS * np.max(hist), 4096))  # fixed message size: 2.5x the expected halo
     n_max = int(per * 1.25) + 4 * halo_cap + 1024
     backend = HipSlabBackend(params, n_max, device, halo_cap)
     slab = SlabSolver(backend, params, bounds, group)

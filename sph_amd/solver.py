@@ -111,7 +111,11 @@ class Solver:
         _lib.check(self.L.sphhip_set_tuning(self.h, int(tile_cells), int(pair_cap)))
 
     def set_stream(self, stream_ptr):
-        _lib.check(self.L.sphhip_set_stream(self.h, ctypes.c_void_p(stream_ptr)))
+        """Run on a caller-owned HIP stream; 0 / None selects the device's default (null) stream."""
+        if not stream_ptr:
+            _lib.check(self.L.sphhip_use_default_stream(self.h))
+        else:
+            _lib.check(self.L.sphhip_set_stream(self.h, ctypes.c_void_p(stream_ptr)))
 
     def set_profiling(self, on):
         _lib.check(self.L.sphhip_set_profiling(self.h, 1 if on else 0))
@@ -135,6 +139,17 @@ class Solver:
                                            int(cap_left), ctypes.byref(nl), ctypes.c_void_p(d_right), int(cap_right),
                                            ctypes.byref(nr)))
         return nl.value, nr.value
+
+    def pack_halo_async(self, send_hi_left, send_lo_right, d_msg_left, d_msg_right, cap):
+        _lib.check(self.L.sphhip_pack_halo_async(self.h, int(send_hi_left), int(send_lo_right),
+                                                 ctypes.c_void_p(d_msg_left), ctypes.c_void_p(d_msg_right), int(cap)))
+
+    def finish_exchange(self, d_msg_left, d_msg_right, d_recv_left, d_recv_right, cap):
+        out = (ctypes.c_int * 5)()
+        _lib.check(self.L.sphhip_finish_exchange(self.h, ctypes.c_void_p(d_msg_left), ctypes.c_void_p(d_msg_right),
+                                                 ctypes.c_void_p(d_recv_left), ctypes.c_void_p(d_recv_right), int(cap),
+                                                 out))
+        return list(out)
 
     def keep_columns(self, lo, hi):
         _lib.check(self.L.sphhip_keep_columns(self.h, int(lo), int(hi)))

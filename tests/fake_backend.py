@@ -23,8 +23,25 @@ class FakeSlabBackend:
         self.device = torch.device("cpu")
         self.lo, self.hi = 0, self.drv.nx
 
-    def new_buffer(self, n):
-        return torch.zeros((n, 5), dtype=torch.int32)
+    CAP = 4096
+
+    def recv_buffers(self):
+        self.recv_l = torch.zeros((self.CAP + 1, 5), dtype=torch.int32)
+        self.recv_r = torch.zeros((self.CAP + 1, 5), dtype=torch.int32)
+        return self.recv_l, self.recv_r
+
+    def _message(self, rec):
+        assert rec.shape[0] <= self.CAP
+        m = torch.zeros((self.CAP + 1, 5), dtype=torch.int32)
+        m[0, 0] = rec.shape[0]
+        m[1:1 + rec.shape[0]] = rec
+        return m
+
+    def finish(self, has_left, has_right):
+        if has_left:
+            self.append(self.recv_l[1:1 + int(self.recv_l[0, 0])])
+        if has_right:
+            self.append(self.recv_r[1:1 + int(self.recv_r[0, 0])])
 
     def set_owned(self, lo, hi):
         self.lo, self.hi = lo, hi
@@ -41,11 +58,11 @@ class FakeSlabBackend:
             self.a, self.ids = self.a[self.owned_mask], self.ids[self.owned_mask]
             self.owned_mask = None
 
-    def pack(self, send_hi_left, send_lo_right):
+    def pack(self, send_hi_left, send_lo_right, has_left, has_right):
         self.drop_ghosts()
         col = grid_column(self.a["pos"][:, 0], self.params, self.drv)
-        left = self._records(col < send_hi_left)
-        right = self._records(col >= send_lo_right)
+        left = self._message(self._records(col < send_hi_left)) if has_left else None
+        right = self._message(self._records(col >= send_lo_right)) if has_right else None
         keep = (col >= self.lo - HALO_COLS) & (col < self.hi + HALO_COLS)  # fresh migrants stay as ghosts
         self.a, self.ids = self.a[keep], self.ids[keep]
         return left, right
@@ -54,7 +71,7 @@ class FakeSlabBackend:
         if rec.shape[0] == 0:
             return
         self.drop_ghosts()
-        r = rec.numpy().view(np.uint8).reshape(-1).view(HALO_DTYPE)
+        r = np.ascontiguousarray(rec.numpy()).view(np.uint8).reshape(-1).view(HALO_DTYPE)
         b = np.zeros(len(r), PARTICLE_DTYPE)
         b["pos"], b["vel"] = r["pos"], r["vel"]
         b["density"] = self.params.rest_density
