@@ -179,19 +179,21 @@ int sphhip_set_owned_columns(SphCtx* ctx, int col_lo, int col_hi);
 int sphhip_pack_halo(SphCtx* ctx, int send_hi_left, int send_lo_right,
                      void* d_left, int cap_left, int* n_left,
                      void* d_right, int cap_right, int* n_right);
-/* The same split without a host synchronisation, for a fixed-size exchange: d_msg_left /
+/* The same split WITHOUT a host synchronisation, for a fixed-size exchange: d_msg_left /
  * d_msg_right are device buffers of (cap + 1) 20-byte records whose record 0 is a header (word 0 =
  * number of records that follow); either may be NULL (no neighbour on that side).  The messages
- * can be sent as they are, stream-ordered behind this call.  Must be followed by
- * sphhip_finish_exchange before any other call on the context. */
+ * can be sent as they are, stream-ordered behind this call.  From here on the particle count is
+ * known on the device only (kernels read it there; launches are sized by the capacity) until a
+ * call that needs it on the host synchronises, e.g. sphhip_sync_counts, sphhip_download. */
 int sphhip_pack_halo_async(SphCtx* ctx, int send_hi_left, int send_lo_right, void* d_msg_left, void* d_msg_right,
                            int cap);
-/* Completes the exchange with ONE stream synchronisation: reads back the kept count and the
- * headers of the two sent and the two received messages (counts5 = {sent left, sent right,
- * received left, received right, kept}; may be NULL), then appends the received records.
- * Fails with SPHHIP_ECAPACITY if any message overflowed `cap`. */
-int sphhip_finish_exchange(SphCtx* ctx, const void* d_msg_left, const void* d_msg_right, const void* d_recv_left,
-                           const void* d_recv_right, int cap, int* counts5);
+/* Appends the records of a received fixed-size message (header + up to cap records, device
+ * memory), reading the count from its header on the device: no host synchronisation. */
+int sphhip_append_message(SphCtx* ctx, const void* d_msg, int cap);
+/* Synchronises the stream, returns the particle count (n may be NULL) and reports, as
+ * SPHHIP_ECAPACITY, any overflow (halo message buffer, context capacity) that happened in the
+ * asynchronous calls since the last synchronisation. */
+int sphhip_sync_counts(SphCtx* ctx, int* n);
 /* Drops every particle whose column is outside [col_lo, col_hi); sends nothing. */
 int sphhip_keep_columns(SphCtx* ctx, int col_lo, int col_hi);
 /* Drops the ghost copies left over from the last step on a slab (particles that were outside the
@@ -225,6 +227,10 @@ enum {
 };
 /* When enabled, every phase is bracketed by HIP events on the context's stream. */
 int sphhip_set_profiling(SphCtx* ctx, int enable);
+/* Same, for the phases whose bit (1u << SPHHIP_PH_*) is set only: event records between
+ * back-to-back small kernels cost ~10 % of a step at 1M particles, one pair around the dominant
+ * kernel costs nothing measurable. */
+int sphhip_set_profiling_mask(SphCtx* ctx, unsigned phase_mask);
 /* Sums since the last reset: milliseconds and launches per phase (arrays of SPHHIP_PH_COUNT). */
 int sphhip_get_phase_times(SphCtx* ctx, float* ms, int* launches);
 int sphhip_reset_phase_times(SphCtx* ctx);

@@ -26,7 +26,7 @@ static int fail(int code, const char* msg) {
 
 // ---- phase timing ---------------------------------------------------------------------------
 void sph_phase_begin(SphCtx* c, int ph) {
-    if (!c->profiling) return;
+    if (!c->profiling || !((c->profile_mask >> ph) & 1u)) return;
     PhaseTimer& t = c->timer;
     if (t.used[ph] == t.start[ph].size()) {
         hipEvent_t a, b;
@@ -38,7 +38,7 @@ void sph_phase_begin(SphCtx* c, int ph) {
 }
 
 void sph_phase_end(SphCtx* c, int ph) {
-    if (!c->profiling) return;
+    if (!c->profiling || !((c->profile_mask >> ph) & 1u)) return;
     PhaseTimer& t = c->timer;
     if (t.used[ph] >= t.stop[ph].size()) return;
     hipEventRecord(t.stop[ph][t.used[ph]], c->stream);
@@ -214,6 +214,10 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     ok(dmalloc(&c->digit_total, 2 * SORT_RADIX));
     ok(dmalloc(&c->scan_tmp, (size_t)(c->ncell + 1 + 2047) / 2048 + 1));
     ok(dmalloc(&c->counters, 64));
+    if (e == hipSuccess) ok(hipMemset(c->counters, 0, sizeof(int) * 64));
+    c->d_err = c->counters + 16;
+    c->n_ring = c->counters + 32;
+    c->d_n = c->n_ring;
     ok(hipMalloc(&c->staging, std::max<size_t>(n * SPHHIP_PARTICLE_BYTES, 64)));
     if (e != hipSuccess) {
         free_all(c);
@@ -324,8 +328,11 @@ extern "C" int sphhip_upload(SphCtx* c, const void* aos28, int n, int id_base) {
                            n, (uint32_t)id_base, c->pos, c->vel, c->rho, c->prs, c->idv);
         LAUNCH_CHECK();
     }
+    {
+        int rc = sph_set_n_host(c, n);
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));  // the host buffer is only borrowed for the call
-    c->n = n;
     c->have_state = true;
     c->grid_valid = false;
     c->counts_valid = false;
@@ -336,6 +343,11 @@ extern "C" int sphhip_upload(SphCtx* c, const void* aos28, int n, int id_base) {
 static int download_impl(SphCtx* c, void* aos28, int* ids, int n) {
     if (!c || (!aos28 && n > 0)) return fail(SPHHIP_EINVAL, "sphhip_download: null argument");
     if (!c->have_state) return fail(SPHHIP_ESTATE, "sphhip_download: nothing uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    {
+        int rc = sph_sync_n(c);
+        if (rc) return rc;
+    }
     if (n != c->n) return fail(SPHHIP_EINVAL, "sphhip_download: n differs from the particle count");
     if (n == 0) return SPHHIP_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -366,8 +378,10 @@ extern "C" int sphhip_download_ids(SphCtx* c, void* aos28, int* ids, int n) { re
 
 extern "C" int sphhip_count(SphCtx* c, int* n) {
     if (!c || !n) return fail(SPHHIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sph_sync_n(c);
     *n = c->n;
-    return SPHHIP_OK;
+    return rc;
 }
 
 // ---- phases ---------------------------------------------------------------------------------
@@ -375,8 +389,15 @@ extern "C" int sphhip_count(SphCtx* c, int* n) {
     do {                                                                         \
         if (!(c)) return fail(SPHHIP_EINVAL, "null context");                    \
         if (!(c)->have_state) return fail(SPHHIP_ESTATE, "no particles uploaded"); \
-        if ((c)->n_pending) return fail(SPHHIP_ESTATE, "exchange in flight: call sphhip_finish_exchange first"); \
         HIP_TRY(hipSetDevice((c)->device));                                      \
+    } while (0)
+
+// for calls that need the particle count on the host
+#define NEED_EXACT(c)                    \
+    do {                                 \
+        NEED_STATE(c);                   \
+        int _rc = sph_sync_n(c);         \
+        if (_rc) return _rc;             \
     } while (0)
 
 extern "C" int sphhip_build_grid(SphCtx* c) {
@@ -423,7 +444,7 @@ extern "C" int sphhip_step(SphCtx* c, float mx, float my, float strength, int ns
 
 // ---- diagnostics ----------------------------------------------------------------------------
 extern "C" int sphhip_get_cells(SphCtx* c, int* keys, int* order, int* cell_start, int* cell_end) {
-    NEED_STATE(c);
+    NEED_EXACT(c);
     if (!c->grid_valid) return fail(SPHHIP_ESTATE, "sphhip_get_cells: no valid grid (positions changed since the last build)");
     const int n = c->n;
     if (keys && n) HIP_TRY(hipMemcpyAsync(keys, c->keys, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
@@ -457,7 +478,7 @@ static int fetch_counts_sorted_by_id(SphCtx* c, std::vector<int>& cnt, std::vect
 }
 
 extern "C" int sphhip_get_neighbor_counts(SphCtx* c, int* counts, int n) {
-    NEED_STATE(c);
+    NEED_EXACT(c);
     if (!counts && n > 0) return fail(SPHHIP_EINVAL, "null argument");
     if (n != c->n) return fail(SPHHIP_EINVAL, "sphhip_get_neighbor_counts: n differs from the particle count");
     if (!c->counts_valid || !c->grid_valid)
@@ -474,7 +495,7 @@ extern "C" int sphhip_get_neighbor_counts(SphCtx* c, int* counts, int n) {
 }
 
 extern "C" int sphhip_get_pair_count(SphCtx* c, long long* pairs) {
-    NEED_STATE(c);
+    NEED_EXACT(c);
     if (!pairs) return fail(SPHHIP_EINVAL, "null argument");
     if (!c->counts_valid) return fail(SPHHIP_ESTATE, "sphhip_get_pair_count: no density pass yet");
     std::vector<int> cnt(c->n);
@@ -506,11 +527,76 @@ struct HaloRec {
 };
 static_assert(sizeof(HaloRec) == 20, "halo record");
 
+// ---- the particle count lives on the device ---------------------------------------------------
+// Slab steps change the particle count every step (migration, ghosts).  To keep the host from
+// synchronising once per step the count is a device word (c->d_n, one slot of a small ring so that
+// a kernel can read the old count and write the new one without a race); kernels read it
+// themselves and launches are sized by an upper bound (sph_n_grid).  The host value c->n is exact
+// only while c->n_exact; sph_sync_n reads it back (one stream synchronisation) when a caller needs it.
+enum { SPH_ERR_HALO_OVERFLOW = 1, SPH_ERR_MSG_BAD = 2, SPH_ERR_CAPACITY = 4 };
+
+static int* n_slot_next(SphCtx* c) { return c->n_ring + ((c->n_slot + 1) & 7); }
+static void n_advance(SphCtx* c) {
+    c->n_slot = (c->n_slot + 1) & 7;
+    c->d_n = c->n_ring + c->n_slot;
+}
+
+int sph_set_n_host(SphCtx* c, int n) {
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_n, n, 1, c->stream));
+    c->n = n;
+    c->n_exact = true;
+    return SPHHIP_OK;
+}
+
+int sph_sync_n(SphCtx* c) {
+    if (c->n_exact) return SPHHIP_OK;
+    int h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&h[0], c->d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h[1], c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n = h[0];
+    c->n_exact = true;
+    if (h[1]) {
+        HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+        if (h[1] & SPH_ERR_CAPACITY) return fail(SPHHIP_ECAPACITY, "particle capacity of the context exceeded during asynchronous steps (particles were dropped)");
+        if (h[1] & SPH_ERR_HALO_OVERFLOW) return fail(SPHHIP_ECAPACITY, "halo message buffer too small during asynchronous steps (records were dropped)");
+        return fail(SPHHIP_ECAPACITY, "received halo message with a bad record count");
+    }
+    return SPHHIP_OK;
+}
+
 // Classifies every particle by the column of its current position: copies it to the left buffer
 // if col < send_hi_left, to the right buffer if col >= send_lo_right, and keeps it (compacted into
 // the *_o arrays) if keep_lo <= col < keep_hi.  Slot order of the outputs is arbitrary (atomics):
 // the next grid build sorts by (key, id), so results do not depend on it.
-__global__ __launch_bounds__(256) void k_split(DevConsts c, int n, const float2* __restrict__ pos,
+constexpr int SPLIT_THREADS = 1024;
+
+// One output stream of k_split: every lane with `flag` gets a unique slot.  Slots are claimed with
+// ONE global atomic per workgroup (wave ballots -> LDS -> atomicAdd by one lane): a single-address
+// atomic per wave would serialise at ~11 ns each (190 us per million particles, measured).
+__device__ __forceinline__ int split_claim(bool flag, int* __restrict__ counter, int* s_cnt /*[16]*/, int* s_base) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < SPLIT_THREADS / 64; w++) {
+            int v = s_cnt[w];
+            s_cnt[w] = tot;
+            tot += v;
+        }
+        *s_base = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    int slot = *s_base + s_cnt[wave] + in_wave;
+    __syncthreads();
+    return slot;
+}
+
+__global__ __launch_bounds__(SPLIT_THREADS) void k_split(DevConsts c, const int* __restrict__ d_n,
+                                                const float2* __restrict__ pos,
                                                 const float2* __restrict__ vel, const float* __restrict__ rho,
                                                 const float* __restrict__ prs, const uint32_t* __restrict__ idv,
                                                 int send_hi_left, int send_lo_right, int keep_lo, int keep_hi,
@@ -520,52 +606,75 @@ __global__ __launch_bounds__(256) void k_split(DevConsts c, int n, const float2*
                                                 float* __restrict__ rho_o, float* __restrict__ prs_o,
                                                 uint32_t* __restrict__ idv_o, int* __restrict__ cnt_left,
                                                 int* __restrict__ cnt_right, int* __restrict__ cnt_keep,
-                                                const int* __restrict__ cell_start, int slice_lo_cell,
-                                                int slice_hi_cell) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+                                                int* __restrict__ err, const int* __restrict__ cell_start,
+                                                int slice_lo_cell, int slice_hi_cell) {
+    __shared__ int s_cnt[SPLIT_THREADS / 64];
+    __shared__ int s_base;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = i < *d_n;
     // After a step on a slab the state still holds the ghost copies (unmoved).  Slots are still in
     // the order of that step's sort, so the particles this rank integrated are exactly the slot
     // range of its owned columns; everything else is a stale ghost and is dropped here.
-    if (cell_start && (i < cell_start[slice_lo_cell] || i >= cell_start[slice_hi_cell])) return;
-    float2 p = pos[i], v = vel[i];
-    uint32_t w = idv[i];
-    int col = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
-    HaloRec r = {p.x, p.y, v.x, v.y, w};
-    if (col < send_hi_left) {
-        int k = atomicAdd(cnt_left, 1);
-        if (k < cap_left) left[k] = r;
+    if (live && cell_start && (i < cell_start[slice_lo_cell] || i >= cell_start[slice_hi_cell])) live = false;
+    float2 p = make_float2(0.0f, 0.0f), v = p;
+    uint32_t w = 0;
+    int col = 0;
+    if (live) {
+        p = pos[i];
+        v = vel[i];
+        w = idv[i];
+        col = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
     }
-    if (col >= send_lo_right) {
-        int k = atomicAdd(cnt_right, 1);
-        if (k < cap_right) right[k] = r;
+    const HaloRec r = {p.x, p.y, v.x, v.y, w};
+    const bool to_left = live && col < send_hi_left;
+    const bool to_right = live && col >= send_lo_right;
+    const bool keep = live && col >= keep_lo && col < keep_hi;
+    if (__syncthreads_or(to_left)) {  // uniform over the workgroup
+        int k = split_claim(to_left, cnt_left, s_cnt, &s_base);
+        if (to_left) {
+            if (k < cap_left) left[k] = r;
+            else atomicOr(err, SPH_ERR_HALO_OVERFLOW);
+        }
     }
-    if (col >= keep_lo && col < keep_hi) {
-        int k = atomicAdd(cnt_keep, 1);
-        pos_o[k] = p;
-        vel_o[k] = v;
-        rho_o[k] = rho[i];
-        prs_o[k] = prs[i];
-        idv_o[k] = w;
+    if (__syncthreads_or(to_right)) {
+        int k = split_claim(to_right, cnt_right, s_cnt, &s_base);
+        if (to_right) {
+            if (k < cap_right) right[k] = r;
+            else atomicOr(err, SPH_ERR_HALO_OVERFLOW);
+        }
+    }
+    if (__syncthreads_or(keep)) {
+        int k = split_claim(keep, cnt_keep, s_cnt, &s_base);
+        if (keep) {
+            pos_o[k] = p;
+            vel_o[k] = v;
+            rho_o[k] = rho[i];
+            prs_o[k] = prs[i];
+            idv_o[k] = w;
+        }
     }
 }
 
-// Enqueues the split.  Counters: cnt_left / cnt_right may live in the message headers (fixed-size
-// exchange) or in c->counters[0..1]; the kept count always goes to c->counters[2].
+// Enqueues the split (no host synchronisation).  cnt_left / cnt_right live in the message headers
+// (fixed-size exchange) or in c->counters[0..1]; the kept count becomes the new device-side n.
 static int split_enqueue(SphCtx* c, int send_hi_left, int send_lo_right, int keep_lo, int keep_hi, HaloRec* d_left,
                          int cap_left, int* cnt_left, HaloRec* d_right, int cap_right, int* cnt_right) {
+    int* keep = n_slot_next(c);
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(int) * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(keep, 0, sizeof(int), c->stream));
     if (cnt_left != c->counters) HIP_TRY(hipMemsetAsync(cnt_left, 0, sizeof(HaloRec), c->stream));
     if (cnt_right != c->counters + 1) HIP_TRY(hipMemsetAsync(cnt_right, 0, sizeof(HaloRec), c->stream));
-    const int n = c->n;
-    if (n > 0) {
-        hipLaunchKernelGGL(k_split, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dc, n, c->pos, c->vel, c->rho,
-                           c->prs, c->idv, send_hi_left, send_lo_right, keep_lo, keep_hi, d_left, cap_left, d_right,
-                           cap_right, c->pos2, c->vel2, c->rho2, c->prs2, c->idv2, cnt_left, cnt_right,
-                           c->counters + 2, c->slice_valid ? c->cell_start : nullptr, c->slice_lo * c->dc.ny,
+    const int ng = sph_n_grid(c);
+    if (ng > 0) {
+        hipLaunchKernelGGL(k_split, dim3((ng + SPLIT_THREADS - 1) / SPLIT_THREADS), dim3(SPLIT_THREADS), 0, c->stream, c->dc, c->d_n, c->pos, c->vel,
+                           c->rho, c->prs, c->idv, send_hi_left, send_lo_right, keep_lo, keep_hi, d_left, cap_left,
+                           d_right, cap_right, c->pos2, c->vel2, c->rho2, c->prs2, c->idv2, cnt_left, cnt_right, keep,
+                           c->d_err, c->slice_valid ? c->cell_start : nullptr, c->slice_lo * c->dc.ny,
                            c->slice_hi * c->dc.ny);
         LAUNCH_CHECK();
     }
+    n_advance(c);
+    c->n_exact = false;
     std::swap(c->pos, c->pos2);
     std::swap(c->vel, c->vel2);
     std::swap(c->rho, c->rho2);
@@ -574,7 +683,6 @@ static int split_enqueue(SphCtx* c, int send_hi_left, int send_lo_right, int kee
     c->grid_valid = false;
     c->counts_valid = false;
     c->slice_valid = false;
-    c->n_pending = true;  // c->n is stale until the kept count has been read back
     return SPHHIP_OK;
 }
 
@@ -585,26 +693,13 @@ static int split_impl(SphCtx* c, int send_hi_left, int send_lo_right, int keep_l
     int rc = split_enqueue(c, send_hi_left, send_lo_right, keep_lo, keep_hi, (HaloRec*)d_left, cap_left, c->counters,
                            (HaloRec*)d_right, cap_right, c->counters + 1);
     if (rc) return rc;
-    int h[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(h, c->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->n = h[2];
-    c->n_pending = false;
-    if (h[0] > cap_left || h[1] > cap_right) return fail(SPHHIP_ECAPACITY, "sphhip_pack_halo: halo buffer too small");
+    int h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h, c->counters, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
+    rc = sph_sync_n(c);  // synchronises the stream
+    if (rc) return rc;
     *n_left = h[0];
     *n_right = h[1];
     return SPHHIP_OK;
-}
-
-// ---- fixed-size exchange: one host synchronisation per step --------------------------------
-__global__ void k_gather_counts(const int* a, const int* b, const int* c2, const int* d, const int* keep, int* out) {
-    if (threadIdx.x == 0) {
-        out[0] = a ? a[0] : 0;
-        out[1] = b ? b[0] : 0;
-        out[2] = c2 ? c2[0] : 0;
-        out[3] = d ? d[0] : 0;
-        out[4] = keep[0];
-    }
 }
 
 extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_right, void* d_msg_left,
@@ -617,31 +712,6 @@ extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_r
     return split_enqueue(c, l ? send_hi_left : -1, r ? send_lo_right : 0x7fffffff, c->col_lo - SPHHIP_HALO_COLS,
                          c->col_hi + SPHHIP_HALO_COLS, l ? l + 1 : nullptr, l ? cap : 0, l ? (int*)l : c->counters,
                          r ? r + 1 : nullptr, r ? cap : 0, r ? (int*)r : c->counters + 1);
-}
-
-static int append_records(SphCtx* c, const void* d_records, int n);
-
-extern "C" int sphhip_finish_exchange(SphCtx* c, const void* d_msg_left, const void* d_msg_right,
-                                      const void* d_recv_left, const void* d_recv_right, int cap, int* counts5) {
-    if (!c) return fail(SPHHIP_EINVAL, "null context");
-    HIP_TRY(hipSetDevice(c->device));
-    if (!c->n_pending) return fail(SPHHIP_ESTATE, "sphhip_finish_exchange: no exchange in flight");
-    hipLaunchKernelGGL(k_gather_counts, dim3(1), dim3(64), 0, c->stream, (const int*)d_msg_left, (const int*)d_msg_right,
-                       (const int*)d_recv_left, (const int*)d_recv_right, c->counters + 2, c->counters + 8);
-    LAUNCH_CHECK();
-    int h[5] = {0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(h, c->counters + 8, sizeof(int) * 5, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->n = h[4];
-    c->n_pending = false;
-    if (counts5) memcpy(counts5, h, sizeof h);
-    if (h[0] > cap || h[1] > cap) return fail(SPHHIP_ECAPACITY, "sphhip_finish_exchange: halo message buffer too small");
-    if (h[2] < 0 || h[3] < 0 || h[2] > cap || h[3] > cap)
-        return fail(SPHHIP_ECAPACITY, "sphhip_finish_exchange: received halo message exceeds the buffer");
-    int rc = SPHHIP_OK;
-    if (d_recv_left && h[2]) rc = append_records(c, (const HaloRec*)d_recv_left + 1, h[2]);
-    if (!rc && d_recv_right && h[3]) rc = append_records(c, (const HaloRec*)d_recv_right + 1, h[3]);
-    return rc;
 }
 
 extern "C" int sphhip_pack_halo(SphCtx* c, int send_hi_left, int send_lo_right, void* d_left, int cap_left,
@@ -667,12 +737,31 @@ extern "C" int sphhip_drop_ghosts(SphCtx* c) {
     return split_impl(c, -1, 0x7fffffff, 0, c->dc.nx, nullptr, 0, &nl, nullptr, 0, &nr);
 }
 
-__global__ __launch_bounds__(256) void k_append(const HaloRec* __restrict__ rec, int n, int at,
+// Appends records behind the current particles.  The record count is either immediate or the
+// header word of a fixed-size message; the new particle count goes to the next ring slot.
+__global__ __launch_bounds__(256) void k_append(const HaloRec* __restrict__ rec, const int* __restrict__ d_cnt,
+                                                 int cnt_imm, int cap, const int* __restrict__ n_in,
+                                                 int* __restrict__ n_out, int n_max, int* __restrict__ err,
                                                  float2* __restrict__ pos, float2* __restrict__ vel,
                                                  float* __restrict__ rho, float* __restrict__ prs,
                                                  uint32_t* __restrict__ idv, float rest_density) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    int cnt = d_cnt ? *d_cnt : cnt_imm;
+    const int at = *n_in;
+    int flag = 0;
+    if (cnt < 0 || cnt > cap) {
+        flag |= SPH_ERR_MSG_BAD;
+        cnt = cnt < 0 ? 0 : cap;
+    }
+    if (at + cnt > n_max) {
+        flag |= SPH_ERR_CAPACITY;
+        cnt = n_max - at;
+    }
+    if (i == 0) {
+        *n_out = at + cnt;
+        if (flag) atomicOr(err, flag);
+    }
+    if (i >= cnt) return;
     HaloRec r = rec[i];
     pos[at + i] = make_float2(r.x, r.y);
     vel[at + i] = make_float2(r.vx, r.vy);
@@ -681,30 +770,52 @@ __global__ __launch_bounds__(256) void k_append(const HaloRec* __restrict__ rec,
     idv[at + i] = r.idv;
 }
 
-extern "C" int sphhip_append(SphCtx* c, const void* d_records, int n) {
-    if (!c) return fail(SPHHIP_EINVAL, "null context");
-    if (n < 0 || (n > 0 && !d_records)) return fail(SPHHIP_EINVAL, "sphhip_append: bad argument");
-    if (c->n_pending) return fail(SPHHIP_ESTATE, "sphhip_append: exchange in flight (call sphhip_finish_exchange)");
-    HIP_TRY(hipSetDevice(c->device));
-    return append_records(c, d_records, n);
-}
-
-static int append_records(SphCtx* c, const void* d_records, int n) {
+static int append_enqueue(SphCtx* c, const HaloRec* rec, const int* d_cnt, int cnt_imm, int cap) {
     if (c->slice_valid && c->have_state) {  // stale ghosts of the last step must not mix with new records
         int rc = sphhip_drop_ghosts(c);
         if (rc) return rc;
     }
-    if (c->n + n > c->n_max) return fail(SPHHIP_ECAPACITY, "sphhip_append: exceeds the context capacity");
-    if (n > 0) {
-        hipLaunchKernelGGL(k_append, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const HaloRec*)d_records, n,
-                           c->n, c->pos, c->vel, c->rho, c->prs, c->idv, c->params.rest_density);
-        LAUNCH_CHECK();
-    }
-    c->n += n;
+    int* out = n_slot_next(c);
+    int grid = (cap + 255) / 256;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_append, dim3(grid), dim3(256), 0, c->stream, rec, d_cnt, cnt_imm, cap, c->d_n, out, c->n_max,
+                       c->d_err, c->pos, c->vel, c->rho, c->prs, c->idv, c->params.rest_density);
+    LAUNCH_CHECK();
+    n_advance(c);
     c->have_state = true;
     c->grid_valid = false;
     c->counts_valid = false;
     return SPHHIP_OK;
+}
+
+extern "C" int sphhip_append(SphCtx* c, const void* d_records, int n) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    if (n < 0 || (n > 0 && !d_records)) return fail(SPHHIP_EINVAL, "sphhip_append: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n_exact && c->n + n > c->n_max) return fail(SPHHIP_ECAPACITY, "sphhip_append: exceeds the context capacity");
+    if (n == 0) return SPHHIP_OK;
+    int rc = append_enqueue(c, (const HaloRec*)d_records, nullptr, n, n);
+    if (rc) return rc;
+    if (c->n_exact) c->n += n;  // stays exact: the kernel cannot have clamped
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_append_message(SphCtx* c, const void* d_msg, int cap) {
+    if (!c || !d_msg) return fail(SPHHIP_EINVAL, "sphhip_append_message: null argument");
+    if (cap < 0) return fail(SPHHIP_EINVAL, "sphhip_append_message: negative capacity");
+    HIP_TRY(hipSetDevice(c->device));
+    const HaloRec* m = (const HaloRec*)d_msg;
+    int rc = append_enqueue(c, m + 1, (const int*)m, 0, cap);
+    c->n_exact = false;
+    return rc;
+}
+
+extern "C" int sphhip_sync_counts(SphCtx* c, int* n) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sph_sync_n(c);
+    if (n) *n = c->n;
+    return rc;
 }
 
 __global__ __launch_bounds__(256) void k_col_hist(DevConsts c, int n, const float2* __restrict__ pos,
@@ -715,7 +826,7 @@ __global__ __launch_bounds__(256) void k_col_hist(DevConsts c, int n, const floa
 }
 
 extern "C" int sphhip_column_histogram(SphCtx* c, int* hist) {
-    NEED_STATE(c);
+    NEED_EXACT(c);
     if (!hist) return fail(SPHHIP_EINVAL, "null argument");
     // cell_start is free between steps only when the grid is stale; use keys2 as scratch instead
     int* d_hist = (int*)c->keys2;
@@ -741,6 +852,16 @@ extern "C" int sphhip_set_profiling(SphCtx* c, int enable) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     timer_flush(c);
     c->profiling = enable != 0;
+    c->profile_mask = ~0u;
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_set_profiling_mask(SphCtx* c, unsigned mask) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    timer_flush(c);
+    c->profile_mask = mask;
+    c->profiling = mask != 0;
     return SPHHIP_OK;
 }
 

@@ -12,8 +12,9 @@
 // ---------------------------------------------------------------------------------------------
 // cell hash: key per slot + identity permutation.   R pos 8 B, W key 4 B + idx 4 B per particle
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hash(DevConsts c, const float2* __restrict__ pos, int n,
+__global__ __launch_bounds__(256) void k_hash(DevConsts c, const float2* __restrict__ pos, const int* __restrict__ d_n,
                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ perm) {
+    const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float2 p = pos[i];
@@ -27,9 +28,10 @@ __global__ __launch_bounds__(256) void k_hash(DevConsts c, const float2* __restr
 // Radix sort pass, kernel 1: per-workgroup digit histogram, stored digit-major
 // (block_hist[d * nblocks + b]) so that kernel 2 scans contiguous rows.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys, int n, int shift,
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys, const int* __restrict__ d_n, int shift,
                                                              uint32_t mask, int* __restrict__ block_hist,
                                                              int nblocks) {
+    const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
     __shared__ int hist[SORT_RADIX];
     int tid = threadIdx.x;
     hist[tid] = 0;
@@ -93,9 +95,10 @@ __global__ __launch_bounds__(256) void k_sort_scan_digits(int* __restrict__ digi
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out,
-                                                                uint32_t* __restrict__ vals_out, int n, int shift,
+                                                                uint32_t* __restrict__ vals_out, const int* __restrict__ d_n, int shift,
                                                                 uint32_t mask, const int* __restrict__ block_hist,
                                                                 const int* __restrict__ digit_total, int nblocks) {
+    const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
     __shared__ unsigned short cnt[SORT_ITEMS][4][SORT_RADIX];  // 16 KB
     __shared__ int digit_start[SORT_RADIX];
     __shared__ int global_off[SORT_RADIX];
@@ -176,9 +179,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* _
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cell_marks(const uint32_t* __restrict__ skeys,
                                                      const uint32_t* __restrict__ perm,
-                                                     const uint32_t* __restrict__ idv, int n,
+                                                     const uint32_t* __restrict__ idv, const int* __restrict__ d_n,
                                                      int* __restrict__ cell_start,
                                                      uint32_t* __restrict__ ids_sorted) {
+    const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     uint32_t k = skeys[s];
@@ -243,7 +247,8 @@ __global__ __launch_bounds__(256) void k_sufmin_parts(int* __restrict__ part, in
 }
 
 __global__ __launch_bounds__(256) void k_sufmin_apply(int* __restrict__ a, int len, const int* __restrict__ part,
-                                                       int n) {
+                                                       const int* __restrict__ d_n) {
+    const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
     __shared__ int buf[SCAN_CHUNK];
     __shared__ int wmin[4];
     int base = blockIdx.x * SCAN_CHUNK;
@@ -299,12 +304,13 @@ template <bool CARRY_DENSITY>
 __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict__ skeys,
                                                        const uint32_t* __restrict__ perm,
                                                        const uint32_t* __restrict__ ids_sorted,
-                                                       const int* __restrict__ cell_start, int n,
+                                                       const int* __restrict__ cell_start, const int* __restrict__ d_n,
                                                        const float2* __restrict__ pos, const float2* __restrict__ vel,
                                                        const float* __restrict__ rho, const float* __restrict__ prs,
                                                        const uint32_t* __restrict__ idv, float2* __restrict__ pos_o,
                                                        float2* __restrict__ vel_o, float* __restrict__ rho_o,
                                                        float* __restrict__ prs_o, uint32_t* __restrict__ idv_o) {
+    const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     uint32_t k = skeys[s];
@@ -331,13 +337,13 @@ static inline int ilog2_ceil(unsigned v) {
 }
 
 int sph_grid_build(SphCtx* c, bool carry_density) {
-    const int n = c->n;
+    const int n = sph_n_grid(c);  // exact count, or the capacity while the count is only known on the device
     hipStream_t st = c->stream;
     const int ncell = c->ncell;
     if (n > 0) {
         {
             PhaseScope ps(c, SPHHIP_PH_HASH);
-            hipLaunchKernelGGL(k_hash, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, n, c->keys, c->perm);
+            hipLaunchKernelGGL(k_hash, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, c->d_n, c->keys, c->perm);
             LAUNCH_CHECK();
         }
         {
@@ -351,13 +357,13 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             for (int p = 0; p < passes; p++) {
                 int bits = min(bits_per_pass, key_bits - shift);
                 uint32_t mask = (1u << bits) - 1u;
-                hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(SORT_THREADS), 0, st, c->keys, n, shift, mask,
+                hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(SORT_THREADS), 0, st, c->keys, c->d_n, shift, mask,
                                    c->block_hist, nblocks);
                 hipLaunchKernelGGL(k_sort_scan_rows, dim3(SORT_RADIX), dim3(256), 0, st, c->block_hist, nblocks,
                                    c->digit_total);
                 hipLaunchKernelGGL(k_sort_scan_digits, dim3(1), dim3(256), 0, st, c->digit_total);
                 hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(SORT_THREADS), 0, st, c->keys, c->perm,
-                                   c->keys2, c->perm2, n, shift, mask, c->block_hist, c->digit_total, nblocks);
+                                   c->keys2, c->perm2, c->d_n, shift, mask, c->block_hist, c->digit_total, nblocks);
                 LAUNCH_CHECK();
                 std::swap(c->keys, c->keys2);
                 std::swap(c->perm, c->perm2);
@@ -370,24 +376,24 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
         const int len = ncell + 1;
         HIP_TRY(hipMemsetAsync(c->cell_start, 0x7f, sizeof(int) * (size_t)len, st));
         if (n > 0) {
-            hipLaunchKernelGGL(k_cell_marks, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm, c->idv, n,
+            hipLaunchKernelGGL(k_cell_marks, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm, c->idv, c->d_n,
                                c->cell_start, c->ids_sorted);
         }
         int nparts = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
         hipLaunchKernelGGL(k_sufmin_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp);
         hipLaunchKernelGGL(k_sufmin_parts, dim3(1), dim3(256), 0, st, c->scan_tmp, nparts);
-        hipLaunchKernelGGL(k_sufmin_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp, n);
+        hipLaunchKernelGGL(k_sufmin_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp, c->d_n);
         LAUNCH_CHECK();
     }
     if (n > 0) {
         PhaseScope ps(c, SPHHIP_PH_REORDER);
         if (carry_density)
             hipLaunchKernelGGL(k_rank_reorder<true>, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm,
-                               c->ids_sorted, c->cell_start, n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
+                               c->ids_sorted, c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
                                c->vel2, c->rho2, c->prs2, c->idv2);
         else
             hipLaunchKernelGGL(k_rank_reorder<false>, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm,
-                               c->ids_sorted, c->cell_start, n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
+                               c->ids_sorted, c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
                                c->vel2, c->rho2, c->prs2, c->idv2);
         LAUNCH_CHECK();
         std::swap(c->pos, c->pos2);

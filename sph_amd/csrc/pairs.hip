@@ -549,10 +549,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
 // Stand-alone integrate (serial_integrate, sph.cpp:101-130).  R pos 8 + vel 8 + idv 4, W 16.
 __global__ __launch_bounds__(256) void k_integrate(DevConsts c, float2* __restrict__ pos, float2* __restrict__ vel,
                                                     const uint32_t* __restrict__ idv,
-                                                    const uint32_t* __restrict__ skeys, int n, int use_cols,
-                                                    int own_lo_col, int own_hi_col) {
+                                                    const uint32_t* __restrict__ skeys,
+                                                    const int* __restrict__ d_n, int use_cols, int own_lo_col,
+                                                    int own_hi_col) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= *d_n) return;
     if (idv[i] & SPH_INVALID_BIT) return;
     if (use_cols) {
         int col = (int)skeys[i] / c.ny;
@@ -570,7 +571,7 @@ static TileMap tile_launch_dims(const SphCtx* c, int col_lo, int col_hi) {
 }
 
 int sph_density_launch(SphCtx* c) {
-    if (c->n == 0) return SPHHIP_OK;
+    if (sph_n_grid(c) == 0) return SPHHIP_OK;
     PhaseScope ps(c, SPHHIP_PH_DENSITY);
     // one column wider than the owned range: ghost densities are recomputed locally
     int lo = c->col_lo > 0 ? c->col_lo - 1 : 0;
@@ -587,7 +588,7 @@ int sph_density_launch(SphCtx* c) {
 }
 
 int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate) {
-    if (c->n == 0) return SPHHIP_OK;
+    if (sph_n_grid(c) == 0) return SPHHIP_OK;
     PhaseScope ps(c, SPHHIP_PH_FORCE);
     TileMap tm = tile_launch_dims(c, 0, c->dc.nx);  // all columns: ghost tiles pass through
     const int th = c->pair_threads;
@@ -607,11 +608,11 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
 }
 
 int sph_integrate_launch(SphCtx* c) {
-    if (c->n == 0) return SPHHIP_OK;
+    if (sph_n_grid(c) == 0) return SPHHIP_OK;
     PhaseScope ps(c, SPHHIP_PH_INTEGRATE);
     bool restrict_cols = c->grid_valid && (c->col_lo > 0 || c->col_hi < c->dc.nx);
-    hipLaunchKernelGGL(k_integrate, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->dc, c->pos, c->vel, c->idv,
-                       c->keys, c->n, restrict_cols ? 1 : 0, c->col_lo, c->col_hi);
+    hipLaunchKernelGGL(k_integrate, dim3((sph_n_grid(c) + 255) / 256), dim3(256), 0, c->stream, c->dc, c->pos, c->vel,
+                       c->idv, c->keys, c->d_n, restrict_cols ? 1 : 0, c->col_lo, c->col_hi);
     LAUNCH_CHECK();
     c->grid_valid = false;
     return SPHHIP_OK;

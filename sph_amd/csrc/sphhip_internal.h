@@ -46,14 +46,18 @@ struct SphCtx {
     DevConsts dc;
     int device = 0;
     int n_max = 0;   // particle capacity
-    int n = 0;       // particles currently held
+    int n = 0;       // particles currently held (exact only while n_exact; see ctx.hip)
+    bool n_exact = true;
+    int* n_ring = nullptr;  // device: ring of 8 particle-count words
+    int n_slot = 0;
+    int* d_n = nullptr;     // device: current particle count (= n_ring + n_slot)
+    int* d_err = nullptr;   // device: sticky error bits of asynchronous steps
     int ncell = 0;   // nx * ny
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool have_state = false;
     bool grid_valid = false;
     bool counts_valid = false;
-    bool n_pending = false;      // an asynchronous split is in flight: n is not known on the host yet
     bool slice_valid = false;    // slots of [slice_lo, slice_hi) columns (at the last sort) = owned particles
     int slice_lo = 0, slice_hi = 0;
     int col_lo = 0, col_hi = 0;  // owned columns (default: all)
@@ -80,6 +84,7 @@ struct SphCtx {
     void* staging = nullptr;                     // AoS staging for upload / download (28 B * n_max)
 
     bool profiling = false;
+    unsigned profile_mask = ~0u;  // bit ph: bracket that phase with events
     PhaseTimer timer;
 };
 
@@ -104,6 +109,10 @@ int sph_grid_build(SphCtx* c, bool carry_density);
 int sph_density_launch(SphCtx* c);
 int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate);
 int sph_integrate_launch(SphCtx* c);
+int sph_set_n_host(SphCtx* c, int n);
+int sph_sync_n(SphCtx* c);
+// launch bound for per-particle kernels: the exact count, or the capacity while only the device knows it
+static inline int sph_n_grid(const SphCtx* c) { return c->n_exact ? c->n : c->n_max; }
 int sph_selftest_division(int device, unsigned long long* checked, unsigned long long* mismatches);
 int sph_unpack_aos(SphCtx* c, int n, int id_base);
 int sph_pack_aos(SphCtx* c, int n, uint32_t* d_ids_out);

@@ -41,13 +41,15 @@ SIGNATURES = {
     "sphhip_set_owned_columns": [_vp, _ci, _ci],
     "sphhip_pack_halo": [_vp, _ci, _ci, _vp, _ci, _pi, _vp, _ci, _pi],
     "sphhip_pack_halo_async": [_vp, _ci, _ci, _vp, _vp, _ci],
-    "sphhip_finish_exchange": [_vp, _vp, _vp, _vp, _vp, _ci, _pi],
+    "sphhip_append_message": [_vp, _vp, _ci],
+    "sphhip_sync_counts": [_vp, _pi],
     "sphhip_keep_columns": [_vp, _ci, _ci],
     "sphhip_drop_ghosts": [_vp],
     "sphhip_append": [_vp, _vp, _ci],
     "sphhip_column_histogram": [_vp, _vp],
     "sphhip_selftest_division": [_ci, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)],
     "sphhip_set_profiling": [_vp, _ci],
+    "sphhip_set_profiling_mask": [_vp, ctypes.c_uint],
     "sphhip_get_phase_times": [_vp, _vp, _vp],
     "sphhip_reset_phase_times": [_vp],
     "sphhip_get_pair_count": [_vp, ctypes.POINTER(ctypes.c_longlong)],

@@ -92,11 +92,15 @@ class HipSlabBackend:
         return self.recv_l, self.recv_r
 
     def finish(self, has_left, has_right):
-        """One host sync: read all counts, append what was received."""
-        return self.solver.finish_exchange(self.send_l.data_ptr() if has_left else None,
-                                           self.send_r.data_ptr() if has_right else None,
-                                           self.recv_l.data_ptr() if has_left else None,
-                                           self.recv_r.data_ptr() if has_right else None, self.cap)
+        """Appends what was received; counts stay on the device (no host synchronisation)."""
+        if has_left:
+            self.solver.append_message(self.recv_l.data_ptr(), self.cap)
+        if has_right:
+            self.solver.append_message(self.recv_r.data_ptr(), self.cap)
+
+    def check(self):
+        """Synchronises and raises if a halo buffer or the particle capacity overflowed."""
+        return self.solver.sync_counts()
 
     def append_host(self, rec_np):
         t = torch.from_numpy(np.ascontiguousarray(rec_np).view(np.int32).reshape(-1, 5)).to(self.device)
@@ -220,6 +224,11 @@ class SlabSolver:
 
     def local_count(self):
         return self.backend.n
+
+    def check(self):
+        """Host synchronisation point: raises if any asynchronous step overflowed a buffer."""
+        chk = getattr(self.backend, "check", None)
+        return chk() if chk else self.backend.n
 
 
 def records_from_particles(a, ids):

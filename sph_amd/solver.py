@@ -120,6 +120,13 @@ class Solver:
     def set_profiling(self, on):
         _lib.check(self.L.sphhip_set_profiling(self.h, 1 if on else 0))
 
+    def set_profiling_phases(self, names):
+        """Bracket only the named phases (sph_amd.lib.PH_NAMES) with HIP events."""
+        mask = 0
+        for nm in names:
+            mask |= 1 << _lib.PH_NAMES.index(nm)
+        _lib.check(self.L.sphhip_set_profiling_mask(self.h, mask))
+
     def reset_phase_times(self):
         _lib.check(self.L.sphhip_reset_phase_times(self.h))
 
@@ -144,12 +151,13 @@ class Solver:
         _lib.check(self.L.sphhip_pack_halo_async(self.h, int(send_hi_left), int(send_lo_right),
                                                  ctypes.c_void_p(d_msg_left), ctypes.c_void_p(d_msg_right), int(cap)))
 
-    def finish_exchange(self, d_msg_left, d_msg_right, d_recv_left, d_recv_right, cap):
-        out = (ctypes.c_int * 5)()
-        _lib.check(self.L.sphhip_finish_exchange(self.h, ctypes.c_void_p(d_msg_left), ctypes.c_void_p(d_msg_right),
-                                                 ctypes.c_void_p(d_recv_left), ctypes.c_void_p(d_recv_right), int(cap),
-                                                 out))
-        return list(out)
+    def append_message(self, d_msg, cap):
+        _lib.check(self.L.sphhip_append_message(self.h, ctypes.c_void_p(d_msg), int(cap)))
+
+    def sync_counts(self):
+        v = ctypes.c_int()
+        _lib.check(self.L.sphhip_sync_counts(self.h, ctypes.byref(v)))
+        return v.value
 
     def keep_columns(self, lo, hi):
         _lib.check(self.L.sphhip_keep_columns(self.h, int(lo), int(hi)))
