@@ -244,3 +244,18 @@ def test_scaled_scene_miniatures():
         assert orc.same_bits(got, want)
         ref = O.step_allpairs(params, a.copy(), 5, flags=orc.GAUSS_SEIDEL)  # reference serial semantics
         assert np.abs(got["pos"] - ref["pos"]).max() <= 1e-6
+
+
+def test_division_selftest():
+    """exact_div.h (shared reciprocal + FMA corrections) against hipcc's correctly rounded `/`:
+    every float of the safe range for 1/x, 2^31 random pairs for a/b.  Bar: zero mismatches."""
+    import ctypes
+
+    from sph_amd import lib
+
+    L = lib.load()
+    checked = (ctypes.c_ulonglong * 8)()
+    bad = (ctypes.c_ulonglong * 8)()
+    lib.check(L.sphhip_selftest_division(0, checked, bad))
+    assert checked[0] > 1.3e9 and checked[1] >= 1 << 30
+    assert list(bad)[:5] == [0, 0, 0, 0, 0]
