@@ -42,3 +42,23 @@ __device__ __forceinline__ float sph_div_with_rcp(float a, float b, float y) {
 
 // 1.0f / b
 __device__ __forceinline__ float sph_rcp_exact(float b, float y) { return sph_div_with_rcp(1.0f, b, y); }
+
+// sqrt(x) from one v_rsq_f32 (Goldschmidt iteration + one residual correction): correctly rounded for
+// every float of [SPH_SQRT_LO, SPH_SAFE_HI] (checked exhaustively by sphhip_selftest_division), without
+// the denormal-range scaling and compare/select fix-ups of hipcc's generic sqrtf.  x = 0 and +inf
+// return x.  (The iteration also yields h ~ 1/(2 sqrt x), but 2h is NOT used as the reciprocal seed of
+// the divisions by r_len: the exhaustive self-test showed 1/s going wrong for s = 1.11..1b * 2^k with
+// it -- a tie that only a seed rounded upward resolves -- while rcp + Newton passes for every float.)
+#define SPH_SQRT_LO 8.67361738e-19f /* 2^-60 */
+__device__ __forceinline__ float sph_sqrt_exact(float x) {
+    float r = __builtin_amdgcn_rsqf(x);
+    float g = x * r;
+    float h = 0.5f * r;
+    float e = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, e, g);
+    h = __builtin_fmaf(h, e, h);
+    float d = __builtin_fmaf(-g, g, x);
+    g = __builtin_fmaf(d, h, g);
+    bool special = (x == 0.0f) || (x == __builtin_inff());
+    return special ? x : g;
+}

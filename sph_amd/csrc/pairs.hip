@@ -206,8 +206,23 @@ __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx
                                             const float4 (&aj)[U] /* vx, vy, rho, P of j */, float (&fx)[U],
                                             float (&fy)[U]) {
     float r_len[U], gcoeff[U], pt[U], visc[U], inv_r[U], lcoeff[U];
+    if (FAST) {
+        // r2 below SPH_SQRT_LO (pairs closer than 1e-9, or denormal r2) is outside the validated range
+        // of sph_sqrt_exact: such a group takes the generic sqrtf (wave-uniform, practically never)
+        bool tiny = false;
 #pragma unroll
-    for (int u = 0; u < U; u++) r_len[u] = sqrtf(r2[u]);  // sph.cpp:67
+        for (int u = 0; u < U; u++) tiny = tiny || (r2[u] < SPH_SQRT_LO && r2[u] != 0.0f);
+        if (__any(tiny)) {
+#pragma unroll
+            for (int u = 0; u < U; u++) r_len[u] = sqrtf(r2[u]);  // sph.cpp:67
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) r_len[u] = sph_sqrt_exact(r2[u]);  // sph.cpp:67
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) r_len[u] = sqrtf(r2[u]);  // sph.cpp:67
+    }
     if (FAST) {
         float yr[U], yd[U];
 #pragma unroll
@@ -259,14 +274,20 @@ __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx
         // spiky gradient guard, sph.cpp:16.  `r_len < 1e-6` there is a double compare: true for
         // r_len <= 1e-6f (the float just below 1e-6), false from the next float up.
         bool zero_grad = r_len[u] <= 1e-6f;  // note (*)
-        float gx = zero_grad ? 0.0f : gcoeff[u] * rx[u];
-        float gy = zero_grad ? 0.0f : gcoeff[u] * ry[u];
+        // The guards zero the COEFFICIENT (one select each) instead of both vector components: the
+        // reference returns float2(0, 0); here a component may come out as -0 instead of +0.  That
+        // cannot change the sum: a term of +-0 leaves `force` unchanged (force is never -0: it starts
+        // at +0 and x + (-x) = +0), and next to a non-zero addend the sign of a zero is irrelevant.
+        float gc = zero_grad ? 0.0f : gcoeff[u];
+        float gx = gc * rx[u];
+        float gy = gc * ry[u];
         float pfx = c.neg_mass * pt[u] * gx;  // sph.cpp:70
         float pfy = c.neg_mass * pt[u] * gy;
         float relx = aj[u].x - vix, rely = aj[u].y - viy;  // sph.cpp:71
         bool zero_lj = (r_len[u] >= c.lj_cut) || (r_len[u] < 1e-6f);  // sph.cpp:30
-        float ljx = zero_lj ? 0.0f : lcoeff[u] * rx[u];
-        float ljy = zero_lj ? 0.0f : lcoeff[u] * ry[u];
+        float lc = zero_lj ? 0.0f : lcoeff[u];
+        float ljx = lc * rx[u];
+        float ljy = lc * ry[u];
         fx[u] = pfx + visc[u] * relx + ljx;  // sph.cpp:74-75 (the caller adds it to force)
         fy[u] = pfy + visc[u] * rely + ljy;
     }

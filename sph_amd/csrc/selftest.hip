@@ -70,6 +70,25 @@ __global__ void k_check_div(unsigned long long n, int mode, unsigned long long s
     if (nbad) atomicAdd(bad, nbad);
 }
 
+// every float in [lo_bits, hi_bits]: sqrt, and 1/sqrt(x), a/sqrt(x) through the fused reciprocal
+__global__ void k_check_sqrt(unsigned lo_bits, unsigned hi_bits, unsigned long long* bad) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long nbad = 0;
+    for (unsigned long long b = lo_bits + i; b <= hi_bits; b += stride) {
+        float x = __uint_as_float((unsigned)b);
+        float s = sph_sqrt_exact(x);
+        float y = sph_rcp_refined(s);
+        float want = sqrtf(x);
+        bool ok = __float_as_uint(want) == __float_as_uint(s);
+        float a = rnd_safe(splitmix(b), -30, 24);
+        ok = ok && (__float_as_uint(1.0f / want) == __float_as_uint(sph_div_with_rcp(1.0f, s, y)));
+        ok = ok && (__float_as_uint(a / want) == __float_as_uint(sph_div_with_rcp(a, s, y)));
+        nbad += ok ? 0 : 1;
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 int sph_selftest_division(int device, unsigned long long* checked, unsigned long long* mismatches) {
     HIP_TRY(hipSetDevice(device));
     unsigned long long* d_bad;
@@ -85,6 +104,12 @@ int sph_selftest_division(int device, unsigned long long* checked, unsigned long
     hipLaunchKernelGGL(k_check_div, dim3(4096), dim3(256), 0, 0, npairs, 1, 0x5678ull, d_bad + 2);
     hipLaunchKernelGGL(k_check_div, dim3(4096), dim3(256), 0, 0, npairs, 2, 0x9abcull, d_bad + 3);
     hipLaunchKernelGGL(k_check_div, dim3(256), dim3(256), 0, 0, 1ull << 20, 3, 0xdef0ull, d_bad + 4);
+    unsigned slo, shi;
+    float fslo = SPH_SQRT_LO;
+    std::memcpy(&slo, &fslo, 4);
+    shi = hi;
+    hipLaunchKernelGGL(k_check_sqrt, dim3(4096), dim3(256), 0, 0, slo, shi, d_bad + 5);
+    hipLaunchKernelGGL(k_check_sqrt, dim3(1), dim3(64), 0, 0, 0u, 0u, d_bad + 6);  // x = 0
     LAUNCH_CHECK();
     unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, d_bad, sizeof h, hipMemcpyDeviceToHost));
@@ -94,6 +119,8 @@ int sph_selftest_division(int device, unsigned long long* checked, unsigned long
     checked[2] = npairs;
     checked[3] = npairs;
     checked[4] = 1ull << 20;
-    for (int i = 0; i < 5; i++) mismatches[i] = h[i];
+    checked[5] = (unsigned long long)(shi - slo + 1);
+    checked[6] = 1;
+    for (int i = 0; i < 7; i++) mismatches[i] = h[i];
     return SPHHIP_OK;
 }
