@@ -112,6 +112,8 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("SPH_BENCH_SHARE_GPU") == "1":  # debugging on a one-GPU box: every rank on device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     name = args.workload or "dam1m"
@@ -134,7 +136,11 @@ def main():
         from sph_amd import lib as _lib
         from sph_amd.slab import make_hip_slab
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SPH_BENCH_BACKEND", "nccl")  # "gloo": debugging on a one-GPU box (host-staged messages)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         # weak scaling: the fluid column gets `world` times wider, per-GPU particle count fixed
         params, n_total, hist_fn, make_local = scenes.dam_break_sharded(cols * world, rows)
         drv = _lib.derive(params)
@@ -180,7 +186,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -191,7 +197,7 @@ def main():
     inner.computeDensityPressure()
     pairs_local = inner.pair_count()
     if world > 1:
-        t = torch.tensor([pairs_local], dtype=torch.float64, device="cuda")
+        t = torch.tensor([pairs_local], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t)
         pairs = float(t.item())
     else:

@@ -166,7 +166,10 @@ int sphhip_get_neighbor_counts(SphCtx* ctx, int* counts, int n);
 /* Restrict density / forces / integrate to particles whose cell column is in [col_lo, col_hi)
  * (density is evaluated one column wider on each side so that ghost densities are recomputed
  * locally instead of exchanged, cf. the dens/pres Allgathers MPI_sph.cpp:163-166).
- * Default: all columns. */
+ * Default: all columns.  With a restricted range the context is expected to hold only particles of
+ * the owned columns and of SPHHIP_HALO_COLS ghost columns on each side (what sphhip_pack_halo /
+ * sphhip_append_message produce); position and velocity of particles farther out are undefined
+ * after a step. */
 int sphhip_set_owned_columns(SphCtx* ctx, int col_lo, int col_hi);
 /* Classifies every particle by the grid column of its CURRENT position.  Copies it, as a 20-byte
  * record {x,y,vx,vy,idv}, into d_left if column < send_hi_left and into d_right if column >=

@@ -611,13 +611,18 @@ int sph_density_launch(SphCtx* c) {
 int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate) {
     if (sph_n_grid(c) == 0) return SPHHIP_OK;
     PhaseScope ps(c, SPHHIP_PH_FORCE);
-    TileMap tm = tile_launch_dims(c, 0, c->dc.nx);  // all columns: ghost tiles pass through
+    // owned columns plus the halo on each side (ghost tiles pass their particles through); on a slab
+    // every particle lies inside that range (sphhip_pack_halo keeps nothing farther out), and launching
+    // tiles for the whole global grid would cost one empty workgroup per tile of the other ranks' slabs
+    const int flo = c->col_lo - SPHHIP_HALO_COLS > 0 ? c->col_lo - SPHHIP_HALO_COLS : 0;
+    const int fhi = c->col_hi + SPHHIP_HALO_COLS < c->dc.nx ? c->col_hi + SPHHIP_HALO_COLS : c->dc.nx;
+    TileMap tm = tile_launch_dims(c, flo, fhi);
     const int th = c->pair_threads;
     size_t lds = pair_lds_bytes(c->pair_cap, true, th);
     auto kern = fuse_integrate ? (th == 128 ? k_force<true, 128> : k_force<true, 256>)
                                : (th == 128 ? k_force<false, 128> : k_force<false, 256>);
     hipLaunchKernelGGL(kern, dim3(tm.nblocks), dim3(th), lds, c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv,
-                       c->keys, c->cell_start, c->pos2, c->vel2, 0, tm.ncols, tm.tiles_per_col, c->tile_cells,
+                       c->keys, c->cell_start, c->pos2, c->vel2, flo, tm.ncols, tm.tiles_per_col, c->tile_cells,
                        c->pair_cap, c->col_lo, c->col_hi, mx, my, strength, c->fast_div ? 1 : 0);
     LAUNCH_CHECK();
     std::swap(c->vel, c->vel2);

@@ -94,7 +94,9 @@ def dam_break_sharded(cols, rows=None, spacing=None, base=None):
     base = base or SphParams.reference()
     sp = F(spacing) if spacing else F(base.h / F(4.0))
     w = F(F(cols) * sp)
-    p = _params_for_box(F(4.0) * w, F(2.0) * w, base)
+    # box: 4 x the fluid width, 2 x the fluid height (for cols == rows exactly `dam_break`'s box); the
+    # height does not grow with the number of slabs, so weak scaling keeps the per-rank grid work fixed
+    p = _params_for_box(F(4.0) * w, F(2.0) * F(F(rows) * sp), base)
     xs = (F(p.xmin) + np.arange(cols).astype(np.float32) * sp).astype(np.float32)
     ys = (F(p.ymin) + np.arange(rows).astype(np.float32) * sp).astype(np.float32)
 

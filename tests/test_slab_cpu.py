@@ -100,9 +100,12 @@ def test_grid_column_matches_oracle_keys():
 
 
 def test_sharded_scene_equals_global_scene():
-    params, a = scenes.dam_break(50, 30)
     p2, n_total, hist_fn, make_local = scenes.dam_break_sharded(50, 30)
-    assert bytes(p2) == bytes(params) and n_total == len(a)
+    params, a = scenes.dam_break(50, 30)
+    assert n_total == len(a) and p2.xmax == params.xmax and p2.ymax < params.ymax  # box height follows the rows
+    params = p2
+    ps, _ = scenes.dam_break(40)
+    assert bytes(scenes.dam_break_sharded(40, 40)[0]) == bytes(ps)  # square column: the same box as dam_break
     drv = _lib.derive(params)
     hist = hist_fn(drv)
     assert hist.sum() == n_total
