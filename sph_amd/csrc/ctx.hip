@@ -148,7 +148,7 @@ static hipError_t dmalloc(T** p, size_t count) {
 
 static void free_all(SphCtx* c) {
     void* ptrs[] = {c->pos, c->vel, c->pos2, c->vel2, c->rho, c->prs, c->rho2, c->prs2, c->idv, c->idv2,
-                    c->ncount, c->keys, c->keys2, c->perm, c->perm2, c->ids_sorted, c->cell_start, c->block_hist,
+                    c->ncount, c->nmask, c->keys, c->keys2, c->perm, c->perm2, c->ids_sorted, c->cell_start, c->block_hist,
                     c->digit_total, c->scan_tmp, c->counters, c->staging};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -190,6 +190,7 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
                       safe(p->rest_density) && safe(d.spiky * 1e-8f * 1e-8f) && safe(d.visc_mass * d.visc_lap * 1e-8f);
         if (const char* e = getenv("SPHHIP_FAST_DIV")) c->fast_div = c->fast_div && atoi(e) != 0;
     }
+    if (const char* e = getenv("SPHHIP_USE_MASKS")) c->use_masks = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_PAIR_THREADS")) {
         int v = atoi(e);
         if (v == 128 || v == 256) c->pair_threads = v;
@@ -207,6 +208,7 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     ok(dmalloc(&c->pos, n)); ok(dmalloc(&c->vel, n)); ok(dmalloc(&c->pos2, n)); ok(dmalloc(&c->vel2, n));
     ok(dmalloc(&c->rho, n)); ok(dmalloc(&c->prs, n)); ok(dmalloc(&c->rho2, n)); ok(dmalloc(&c->prs2, n));
     ok(dmalloc(&c->idv, n)); ok(dmalloc(&c->idv2, n)); ok(dmalloc(&c->ncount, n));
+    ok(dmalloc(&c->nmask, n * 8));
     ok(dmalloc(&c->keys, n)); ok(dmalloc(&c->keys2, n)); ok(dmalloc(&c->perm, n)); ok(dmalloc(&c->perm2, n));
     ok(dmalloc(&c->ids_sorted, n));
     ok(dmalloc(&c->cell_start, (size_t)c->ncell + 1));

@@ -31,7 +31,7 @@
 //
 // All LDS of the pair kernels is one dynamic array (16-byte aligned base, no static __shared__ in
 // front of it): [float4 aux[cap]] (force only) [float2 pos[cap]] [int off[MAXC+1]] [int gs[MAXC]]
-// [int wave_tmp[4]] [u16 queue[QCAP*256]] (force only).
+// [int wave_tmp[4]] [u8 queue[QCAP*256]] (force only).
 // ---------------------------------------------------------------------------------------------
 constexpr int PAIR_MAXC = 3 * (PAIR_MAX_TILE_CELLS + 2);  // candidate cells of a tile (<= 256)
 #ifndef FORCE_Q
@@ -48,6 +48,8 @@ constexpr int FORCE_QCAP = FORCE_Q + FORCE_SCAN_UNROLL + FORCE_HEAVY_UNROLL;  //
 // +inf: a lane may read up to PAIR_ROW_PAD records past the end of its range without a bounds test
 // (r2 = +inf fails the distance test); the sentinels inside its range fail the same way.
 constexpr int PAIR_ROW_PAD = 3;
+constexpr int FORCE_MAX_RANGE = 256;  // longest 3x3 stencil range (LDS records) the byte queue can index
+constexpr int PAIR_MASK_WORDS = FORCE_MAX_RANGE / 32;  // in-range bit masks handed from k_density to k_force
 static_assert(FORCE_SCAN_UNROLL - 1 <= PAIR_ROW_PAD, "scan unroll reads past the range end");
 
 struct TileGeom {
@@ -56,7 +58,7 @@ struct TileGeom {
 
 static size_t pair_lds_bytes(int cap, bool force, int threads) {
     size_t b = sizeof(float2) * (size_t)cap + sizeof(int) * (2 * PAIR_MAXC + 1 + 4);
-    if (force) b += sizeof(float4) * (size_t)cap + sizeof(unsigned short) * FORCE_QCAP * threads;
+    if (force) b += sizeof(float4) * (size_t)cap + sizeof(uint8_t) * FORCE_QCAP * threads;
     return b;
 }
 
@@ -138,13 +140,25 @@ __device__ __forceinline__ void density_acc(const DevConsts& c, float2 pi, float
     cnt += in ? 1 : 0;
 }
 
+// same, with the in-range bit shifted into m (m = 2m + in: one add-with-carry) instead of a count
+__device__ __forceinline__ void density_acc_mask(const DevConsts& c, float2 pi, float2 q, float& dens, uint32_t& m) {
+    float rx = pi.x - q.x, ry = pi.y - q.y;
+    float r2 = rx * rx + ry * ry;
+    float term = c.h2 - r2;
+    float w = c.mass * (c.poly6 * term * term * term);
+    bool in = r2 < c.h2;
+    dens += in ? w : 0.0f;
+    m = m + m + (in ? 1u : 0u);
+}
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* __restrict__ pos,
                                                            const uint32_t* __restrict__ skeys,
                                                            const int* __restrict__ cell_start,
                                                            float* __restrict__ rho, float* __restrict__ prs,
-                                                           int* __restrict__ ncount, int col0, int ncols,
-                                                           int tiles_per_col, int tile_cells, int cap) {
+                                                           int* __restrict__ ncount, uint32_t* __restrict__ nmask,
+                                                           int n_max, int col0, int ncols, int tiles_per_col,
+                                                           int tile_cells, int cap) {
     extern __shared__ __align__(16) float4 s_dyn[];
     float2* s_pos = reinterpret_cast<float2*>(s_dyn);
     int* s_off = reinterpret_cast<int*>(s_pos + cap);
@@ -174,8 +188,29 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
         float dens = 0.0f;
         int cnt = 0;
         if (use_lds) {
+            // Four candidates per trip (the row sentinels absorb the overshoot).  The in-range tests are
+            // also shifted into one bit mask per 32 candidates, first candidate in the top bit, and
+            // stored for the force pass (k_force), which then needs no distance scan of its own.
             const int lo = s_off[3 * r0], hi = s_off[3 * r1 + 3] - PAIR_ROW_PAD;
-            for (int j = lo; j < hi; j++) density_acc(c, pi, s_pos[j], dens, cnt);  // sentinels: r2 = inf
+            int j = lo;
+            for (int w = 0; j < hi; w++) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int grp = 0; grp < 8; grp++) {
+                    if (j < hi) {
+                        float2 q[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) q[u] = s_pos[j + u];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) density_acc_mask(c, pi, q[u], dens, m);
+                        j += 4;
+                    } else {
+                        m <<= 4;
+                    }
+                }
+                cnt += __popc(m);
+                if (w < PAIR_MASK_WORDS) nmask[(size_t)w * n_max + s] = m;
+            }
         } else {
             for (int cc = 3 * r0; cc < 3 * r1 + 3; cc++) {
                 int gs = s_gs[cc], n = cand_count(s_off, cc);
@@ -363,6 +398,48 @@ __device__ __forceinline__ void integrate_one(const DevConsts& c, float2& p, flo
 // Tiles whose column is outside [own_lo_col, own_hi_col) only pass their particles through
 // (ghost columns of a slab).
 // ---------------------------------------------------------------------------------------------
+// Heavy phase of one round: evaluates the qn queued pairs of every lane (byte offsets from `lo` in
+// s_q), FORCE_HEAVY_UNROLL at a time, in queue order.
+template <int THREADS, bool FAST>
+__device__ __forceinline__ void force_heavy(const DevConsts& c, const float2* s_pos, const float4* s_aux,
+                                            uint8_t* s_q, int qn, int lo, int self_off, float2 pi, float2 vi,
+                                            float pres_i, float& fx, float& fy) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < FORCE_HEAVY_UNROLL - 1; u++) s_q[(qn + u) * THREADS + tid] = (uint8_t)self_off;
+    for (int t = 0; __any(t < qn); t += FORCE_HEAVY_UNROLL) {
+        int jj[FORCE_HEAVY_UNROLL];
+        float tx[FORCE_HEAVY_UNROLL], ty[FORCE_HEAVY_UNROLL];
+        float rx[FORCE_HEAVY_UNROLL], ry[FORCE_HEAVY_UNROLL], r2[FORCE_HEAVY_UNROLL];
+        float4 aj[FORCE_HEAVY_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+            int e = s_q[(t + u) * THREADS + tid];
+            jj[u] = lo + ((t < qn) ? e : self_off);  // a lane whose queue is exhausted re-evaluates itself
+        }
+#pragma unroll
+        for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+            float2 q = s_pos[jj[u]];
+            aj[u] = s_aux[jj[u]];
+            rx[u] = pi.x - q.x;
+            ry[u] = pi.y - q.y;
+            r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
+        }
+        force_terms<FORCE_HEAVY_UNROLL, FAST>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, tx, ty);
+        // same order as the sequential sum: force += term(t); force += term(t+1); ...
+#pragma unroll
+        for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+            if (FAST) {
+                fx += tx[u];
+                fy += ty[u];
+            } else {
+                fx = (t + u < qn) ? fx + tx[u] : fx;
+                fy = (t + u < qn) ? fy + ty[u] : fy;
+            }
+        }
+    }
+}
+
 // The per-particle neighbour sum of the force pass over the LDS image, for the whole wave at once.
 // Rounds: (1) every lane scans its candidate range until it has queued FORCE_Q in-range neighbours
 // (cheap distance test only; indices go to a per-lane LDS queue in scan order), (2) all lanes
@@ -377,9 +454,12 @@ __device__ __forceinline__ void integrate_one(const DevConsts& c, float2& p, flo
 // !FAST keeps the reference's `j == i` test (sph.cpp:63) and a predicated accumulation.
 template <int THREADS, bool FAST>
 __device__ __forceinline__ void force_rounds(const DevConsts& c, const float2* s_pos, const float4* s_aux,
-                                             unsigned short* s_q, int j, int hi, int self, float2 pi, float2 vi,
+                                             uint8_t* s_q, int j, int hi, int self, float2 pi, float2 vi,
                                              float pres_i, float& fx, float& fy) {
     const int tid = threadIdx.x;
+    // the queue holds byte offsets from the start of the lane's range (ranges are <= FORCE_MAX_RANGE long)
+    const int lo = j;
+    const int self_off = self - lo;
     while (__any(j < hi)) {
         int qn = 0;
         while (__any((j < hi) && (qn < FORCE_Q))) {
@@ -394,45 +474,47 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const float2* s
                     bool in = !(r2 >= c.h2);  // sph.cpp:66
                     if (!FAST) in = in && (j + u != self);  // sph.cpp:63
                     // branch-free push: the slot is rewritten until a candidate is accepted
-                    s_q[qn * THREADS + tid] = (unsigned short)(j + u);
+                    s_q[qn * THREADS + tid] = (uint8_t)(j + u - lo);
                     qn += in ? 1 : 0;
                 }
                 j += FORCE_SCAN_UNROLL;
             }
         }
-#pragma unroll
-        for (int u = 0; u < FORCE_HEAVY_UNROLL - 1; u++) s_q[(qn + u) * THREADS + tid] = (unsigned short)self;
-        for (int t = 0; __any(t < qn); t += FORCE_HEAVY_UNROLL) {
-            int jj[FORCE_HEAVY_UNROLL];
-            float tx[FORCE_HEAVY_UNROLL], ty[FORCE_HEAVY_UNROLL];
-            float rx[FORCE_HEAVY_UNROLL], ry[FORCE_HEAVY_UNROLL], r2[FORCE_HEAVY_UNROLL];
-            float4 aj[FORCE_HEAVY_UNROLL];
-#pragma unroll
-            for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
-                int e = s_q[(t + u) * THREADS + tid];
-                jj[u] = (t < qn) ? e : self;  // a lane whose queue is exhausted re-evaluates itself
-            }
-#pragma unroll
-            for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
-                float2 q = s_pos[jj[u]];
-                aj[u] = s_aux[jj[u]];
-                rx[u] = pi.x - q.x;
-                ry[u] = pi.y - q.y;
-                r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
-            }
-            force_terms<FORCE_HEAVY_UNROLL, FAST>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, tx, ty);
-            // same order as the sequential sum: force += term(t); force += term(t+1); ...
-#pragma unroll
-            for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
-                if (FAST) {
-                    fx += tx[u];
-                    fy += ty[u];
-                } else {
-                    fx = (t + u < qn) ? fx + tx[u] : fx;
-                    fy = (t + u < qn) ? fy + ty[u] : fy;
+        force_heavy<THREADS, FAST>(c, s_pos, s_aux, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy);
+    }
+}
+
+// The same rounds with the scan replaced by the in-range bit masks k_density left behind (one word per
+// 32 candidates of the lane's range, first candidate in the top bit): a round pops up to FORCE_Q set
+// bits per lane into the queue, one per trip, refilling the current word from global memory (the next
+// word is fetched one refill ahead).  Only for FAST tiles: the masks contain the particle itself.
+template <int THREADS>
+__device__ __forceinline__ void force_rounds_mask(const DevConsts& c, const float2* s_pos, const float4* s_aux,
+                                                  uint8_t* s_q, const uint32_t* __restrict__ mask_col, int n_max,
+                                                  int lo, int nw, int self, float2 pi, float2 vi, float pres_i,
+                                                  float& fx, float& fy) {
+    const int tid = threadIdx.x;
+    const int self_off = self - lo;
+    int w = 0;
+    uint32_t m = 0, m_next = 0;
+    if (nw > 0) m = mask_col[0];
+    if (nw > 1) m_next = mask_col[(size_t)n_max];
+    while (__any(m != 0 || w + 1 < nw)) {
+        int qn = 0;
+        while (__any((m != 0 || w + 1 < nw) && qn < FORCE_Q)) {
+            if ((m != 0 || w + 1 < nw) && qn < FORCE_Q) {
+                if (m == 0) {
+                    w++;
+                    m = m_next;
+                    if (w + 1 < nw) m_next = mask_col[(size_t)(w + 1) * n_max];
                 }
+                const int b = __clz((int)m) & 31;  // m == 0 (an empty word): nothing is pushed
+                s_q[qn * THREADS + tid] = (uint8_t)(32 * w + b);
+                qn += (m != 0) ? 1 : 0;
+                m &= 0x7fffffffu >> b;
             }
         }
+        force_heavy<THREADS, true>(c, s_pos, s_aux, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy);
     }
 }
 
@@ -450,14 +532,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
                                                          float2* __restrict__ pos_o, float2* __restrict__ vel_o,
                                                          int col0, int ncols, int tiles_per_col, int tile_cells,
                                                          int cap, int own_lo_col, int own_hi_col, float mx, float my,
-                                                         float strength, int allow_fast) {
+                                                         float strength, int allow_fast,
+                                                         const uint32_t* __restrict__ nmask, int n_max) {
     extern __shared__ __align__(16) float4 s_dyn[];
     float4* s_aux = s_dyn;
     float2* s_pos = reinterpret_cast<float2*>(s_dyn + cap);
     int* s_off = reinterpret_cast<int*>(s_pos + cap);
     int* s_gs = s_off + PAIR_MAXC + 1;
     int* s_wave = s_gs + PAIR_MAXC;
-    unsigned short* s_q = reinterpret_cast<unsigned short*>(s_wave + 4);
+    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_wave + 4);
 
     int tcol, trow;
     if (!sph_tile_of_block(blockIdx.x, ncols, tiles_per_col, tcol, trow)) return;
@@ -476,11 +559,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
     TileGeom g;
     if (!tile_setup<THREADS>(c, cell_start, col0 + tcol, trow, tile_cells, g, s_off, s_gs, s_wave)) return;
     __syncthreads();
-    const bool use_lds = g.total <= cap;
+    // LDS path: the candidates fit and every stencil range is short enough for the byte queue
+    int too_long = 0;
+    if ((int)threadIdx.x < g.cy1 - g.cy0) {
+        const int cy = g.cy0 + (int)threadIdx.x;
+        const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
+        too_long = (s_off[3 * r1 + 3] - PAIR_ROW_PAD - s_off[3 * r0]) > FORCE_MAX_RANGE;
+    }
+    const bool use_lds = !__syncthreads_or(too_long) && g.total <= cap;
     const float inf = __builtin_inff();
-    bool fast = false;
+    bool fast = false, by_mask = false;
     if (use_lds) {
         int unsafe = allow_fast ? 0 : 1;
+        int no_mask = nmask ? 0 : 1;  // k_density's masks: only if no candidate is invalid or non-finite
         for (int cc = threadIdx.x >> 4; cc < g.ncells; cc += THREADS / 16) {
             int o = s_off[cc], n = cand_count(s_off, cc), gs = s_gs[cc];
             for (int k = threadIdx.x & 15; k < n; k += 16) {
@@ -492,6 +583,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
                 unsafe |= (dj == 0.0f || !sph_safe_operand(dj) || !sph_safe_operand(pj)) ? 1 : 0;
                 // `!particles[j].valid` (sph.cpp:63): an invalid j is staged at +inf so that
                 // r2 = +inf >= H*H skips it with the same compare that skips far particles.
+                no_mask |= (!(fabsf(q.x) < inf) || !(fabsf(q.y) < inf) || (idv[j] & SPH_INVALID_BIT)) ? 1 : 0;
                 if (idv[j] & SPH_INVALID_BIT) q = make_float2(inf, inf);
                 s_pos[o + k] = q;
                 s_aux[o + k] = make_float4(w.x, w.y, dj, pj);
@@ -503,6 +595,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
             s_aux[idx] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
         }
         fast = !__syncthreads_or(unsafe);
+        by_mask = !__syncthreads_or(no_mask) && fast;
     }
 
     // All lanes of a wave stay in the loop together (wave-level votes below); lanes without a
@@ -534,7 +627,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
                 hi = s_off[3 * r1 + 3] - PAIR_ROW_PAD;
                 self = s_off[self_cell] + (s - s_gs[self_cell]);
             }
-            if (fast)
+            if (by_mask)
+                force_rounds_mask<THREADS>(c, s_pos, s_aux, s_q, nmask + (have ? s : 0), n_max, j, (hi - j + 31) >> 5,
+                                           self, pi, vi, pres_i, fx, fy);
+            else if (fast)
                 force_rounds<THREADS, true>(c, s_pos, s_aux, s_q, j, hi, self, pi, vi, pres_i, fx, fy);
             else
                 force_rounds<THREADS, false>(c, s_pos, s_aux, s_q, j, hi, self, pi, vi, pres_i, fx, fy);
@@ -602,9 +698,11 @@ int sph_density_launch(SphCtx* c) {
     size_t lds = pair_lds_bytes(c->pair_cap, false, th);
     auto kern = th == 128 ? k_density<128> : k_density<256>;
     hipLaunchKernelGGL(kern, dim3(tm.nblocks), dim3(th), lds, c->stream, c->dc, c->pos, c->keys, c->cell_start, c->rho,
-                       c->prs, c->ncount, lo, tm.ncols, tm.tiles_per_col, c->tile_cells, c->pair_cap);
+                       c->prs, c->ncount, c->nmask, c->n_max, lo, tm.ncols, tm.tiles_per_col, c->tile_cells, c->pair_cap);
     LAUNCH_CHECK();
     c->counts_valid = true;
+    c->mask_tile_cells = c->tile_cells;
+    c->mask_cap = c->pair_cap;
     return SPHHIP_OK;
 }
 
@@ -619,11 +717,15 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     TileMap tm = tile_launch_dims(c, flo, fhi);
     const int th = c->pair_threads;
     size_t lds = pair_lds_bytes(c->pair_cap, true, th);
+    // the masks of the last density pass describe this grid and this tiling
+    const bool masks_ok = c->use_masks && c->counts_valid && c->grid_valid && c->mask_tile_cells == c->tile_cells &&
+                          c->mask_cap == c->pair_cap;
     auto kern = fuse_integrate ? (th == 128 ? k_force<true, 128> : k_force<true, 256>)
                                : (th == 128 ? k_force<false, 128> : k_force<false, 256>);
     hipLaunchKernelGGL(kern, dim3(tm.nblocks), dim3(th), lds, c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv,
                        c->keys, c->cell_start, c->pos2, c->vel2, flo, tm.ncols, tm.tiles_per_col, c->tile_cells,
-                       c->pair_cap, c->col_lo, c->col_hi, mx, my, strength, c->fast_div ? 1 : 0);
+                       c->pair_cap, c->col_lo, c->col_hi, mx, my, strength, c->fast_div ? 1 : 0,
+                       masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max);
     LAUNCH_CHECK();
     std::swap(c->vel, c->vel2);
     if (fuse_integrate) {

@@ -71,6 +71,9 @@ struct SphCtx {
     float *rho = nullptr, *prs = nullptr, *rho2 = nullptr, *prs2 = nullptr;
     uint32_t *idv = nullptr, *idv2 = nullptr;
     int* ncount = nullptr;  // neighbour counts of the last density pass (slot order)
+    uint32_t* nmask = nullptr;  // in-range bit masks of the last density pass: word w of slot s at [w * n_max + s]
+    int mask_tile_cells = 0, mask_cap = 0;  // tiling the masks were built with
+    bool use_masks = true;      // SPHHIP_USE_MASKS=0: k_force always scans
 
     // grid
     uint32_t *keys = nullptr, *keys2 = nullptr;  // cell key per slot (ping-pong during the sort)
