@@ -108,7 +108,7 @@ int sphhip_get_stream(SphCtx* ctx, void** hip_stream);
 int sphhip_synchronize(SphCtx* ctx);
 const char* sphhip_last_error(void);
 /* Pair-kernel tuning: cells of one grid column per workgroup (1..64) and neighbour candidates
- * staged in LDS per workgroup (64..6144); 0 keeps the current value.  Results do not depend on
+ * staged in LDS per workgroup (64..4608); 0 keeps the current value.  Results do not depend on
  * either (the per-particle summation order is fixed).  No counterpart in the reference
  * (its launch geometry is hard-coded, SPH/sph.cu:219-220). */
 int sphhip_set_tuning(SphCtx* ctx, int tile_cells, int pair_cap);

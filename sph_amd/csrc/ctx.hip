@@ -186,7 +186,8 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
         // inside [SPH_SAFE_LO, SPH_SAFE_HI] of exact_div.h with margin
         auto safe = [](float x) { x = std::fabs(x); return x >= 4e-12f && x <= 2.5e11f; };
         float t = p->h;  // term = h - r_len <= h
-        c->fast_div = safe(d.spiky * t * t) && safe(d.visc_mass * d.visc_lap * t) && safe(p->h) && safe(p->stiffness) &&
+        // (p->h >= 2^-5: k_force's clamp of tiny pair distances relies on h - 2^-30 == h, see force_terms)
+        c->fast_div = p->h >= 0.03125f && safe(d.spiky * t * t) && safe(d.visc_mass * d.visc_lap * t) && safe(p->h) && safe(p->stiffness) &&
                       safe(p->rest_density) && safe(d.spiky * 1e-8f * 1e-8f) && safe(d.visc_mass * d.visc_lap * 1e-8f);
         if (const char* e = getenv("SPHHIP_FAST_DIV")) c->fast_div = c->fast_div && atoi(e) != 0;
     }
@@ -197,7 +198,7 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     }
     if (const char* e = getenv("SPHHIP_PAIR_CAP")) {
         int v = atoi(e);
-        if (v >= 64 && v <= 6144) c->pair_cap = v;
+        if (v >= 64 && v <= 4608) c->pair_cap = v;
     }
     const size_t n = (size_t)n_max;
     const int nblocks = (n_max + SORT_TILE - 1) / SORT_TILE;
@@ -275,7 +276,7 @@ extern "C" int sphhip_set_tuning(SphCtx* c, int tile_cells, int pair_cap) {
     }
     if (3 * (c->tile_cells + 2) > c->pair_threads) c->pair_threads = 256;  // one thread per candidate cell
     if (pair_cap > 0) {
-        if (pair_cap < 64 || pair_cap > 6144) return fail(SPHHIP_EINVAL, "pair_cap out of range [64, 6144]");
+        if (pair_cap < 64 || pair_cap > 4608) return fail(SPHHIP_EINVAL, "pair_cap out of range [64, 4608]");
         c->pair_cap = pair_cap;
     }
     return SPHHIP_OK;

@@ -30,14 +30,19 @@ __device__ __forceinline__ float sph_rcp_refined(float b) {
     return __builtin_fmaf(e, y0, y0);
 }
 
-// a / b given y ~ 1/b (refined): two remainder corrections, then special-case fixup
-__device__ __forceinline__ float sph_div_with_rcp(float a, float b, float y) {
+// a / b given y ~ 1/b (refined): two remainder corrections (Markstein).  Domain: b and a non-zero in the
+// safe range, or a == 0.  Anything else (b = 0, inf, NaN ...) yields NaN / garbage, never a trap.
+__device__ __forceinline__ float sph_div_core(float a, float b, float y) {
     float q0 = a * y;
     float r0 = __builtin_fmaf(-b, q0, a);
     float q1 = __builtin_fmaf(r0, y, q0);
     float r1 = __builtin_fmaf(-b, q1, a);
-    float q2 = __builtin_fmaf(r1, y, q1);
-    return __builtin_amdgcn_div_fixupf(q2, b, a);
+    return __builtin_fmaf(r1, y, q1);
+}
+
+// the same with the hardware's special-case fixup (0, inf, NaN operands behave like `/`)
+__device__ __forceinline__ float sph_div_with_rcp(float a, float b, float y) {
+    return __builtin_amdgcn_div_fixupf(sph_div_core(a, b, y), b, a);
 }
 
 // 1.0f / b
@@ -45,12 +50,14 @@ __device__ __forceinline__ float sph_rcp_exact(float b, float y) { return sph_di
 
 // sqrt(x) from one v_rsq_f32 (Goldschmidt iteration + one residual correction): correctly rounded for
 // every float of [SPH_SQRT_LO, SPH_SAFE_HI] (checked exhaustively by sphhip_selftest_division), without
-// the denormal-range scaling and compare/select fix-ups of hipcc's generic sqrtf.  x = 0 and +inf
-// return x.  (The iteration also yields h ~ 1/(2 sqrt x), but 2h is NOT used as the reciprocal seed of
-// the divisions by r_len: the exhaustive self-test showed 1/s going wrong for s = 1.11..1b * 2^k with
-// it -- a tie that only a seed rounded upward resolves -- while rcp + Newton passes for every float.)
+// the denormal-range scaling and compare/select fix-ups of hipcc's generic sqrtf.  Outside that range
+// (0, denormals, inf) the result is garbage: callers clamp (k_force) or use sph_sqrt_exact.
+// Also returns y = sph_rcp_refined(s), the `y` of sph_div_core(., s, y); the self-test checks 1/s and
+// a/s through it for every x.  (Neither the Goldschmidt by-product 2h nor a Newton step from the v_rsq
+// value can replace that v_rcp: with either, 1/s came out wrong for the 100 roots s = 1.11..1b * 2^k
+// of the range -- a tie that only a seed rounded upward resolves.)
 #define SPH_SQRT_LO 8.67361738e-19f /* 2^-60 */
-__device__ __forceinline__ float sph_sqrt_exact(float x) {
+__device__ __forceinline__ float sph_sqrt_core(float x, float& y) {
     float r = __builtin_amdgcn_rsqf(x);
     float g = x * r;
     float h = 0.5f * r;
@@ -59,6 +66,14 @@ __device__ __forceinline__ float sph_sqrt_exact(float x) {
     h = __builtin_fmaf(h, e, h);
     float d = __builtin_fmaf(-g, g, x);
     g = __builtin_fmaf(d, h, g);
+    y = sph_rcp_refined(g);
+    return g;
+}
+
+// x = 0 and +inf return x
+__device__ __forceinline__ float sph_sqrt_exact(float x) {
+    float y;
+    float g = sph_sqrt_core(x, y);
     bool special = (x == 0.0f) || (x == __builtin_inff());
     return special ? x : g;
 }

@@ -30,12 +30,12 @@
 // slot -- is the canonical summation order, shared with oracle/sph_oracle.c (orc_stencil_ranges).
 //
 // All LDS of the pair kernels is one dynamic array (16-byte aligned base, no static __shared__ in
-// front of it): [float4 aux[cap]] (force only) [float2 pos[cap]] [int off[MAXC+1]] [int gs[MAXC]]
+// front of it): [PairRec rec[cap]] (force) or [float2 pos[cap]] (density) [int off[MAXC+1]] [int gs[MAXC]]
 // [int wave_tmp[4]] [u8 queue[QCAP*256]] (force only).
 // ---------------------------------------------------------------------------------------------
 constexpr int PAIR_MAXC = 3 * (PAIR_MAX_TILE_CELLS + 2);  // candidate cells of a tile (<= 256)
 #ifndef FORCE_Q
-#define FORCE_Q 16  // in-range neighbours gathered per round
+#define FORCE_Q 8  // in-range neighbours gathered per round (scan path only)
 #endif
 #ifndef FORCE_SCAN_UNROLL
 #define FORCE_SCAN_UNROLL 4
@@ -52,13 +52,21 @@ constexpr int FORCE_MAX_RANGE = 256;  // longest 3x3 stencil range (LDS records)
 constexpr int PAIR_MASK_WORDS = FORCE_MAX_RANGE / 32;  // in-range bit masks handed from k_density to k_force
 static_assert(FORCE_SCAN_UNROLL - 1 <= PAIR_ROW_PAD, "scan unroll reads past the range end");
 
+// One staged neighbour candidate of k_force: 32 bytes, so that one shifted index addresses both halves.
+struct __align__(16) PairRec {
+    float4 aux;  // vx, vy, rho, P
+    float2 pos;  // +inf for sentinels and invalid particles
+    float yd;    // refined 1 / rho (sph_rcp_refined), used by FAST tiles
+    float pad;
+};
+
 struct TileGeom {
     int col, cy0, cy1, ylo, yhi, own_lo, own_hi, ncells, total;
 };
 
 static size_t pair_lds_bytes(int cap, bool force, int threads) {
-    size_t b = sizeof(float2) * (size_t)cap + sizeof(int) * (2 * PAIR_MAXC + 1 + 4);
-    if (force) b += sizeof(float4) * (size_t)cap + sizeof(uint8_t) * FORCE_QCAP * threads;
+    size_t b = sizeof(int) * (2 * PAIR_MAXC + 1 + 4);
+    b += force ? sizeof(PairRec) * (size_t)cap + sizeof(uint8_t) * FORCE_QCAP * threads : sizeof(float2) * (size_t)cap;
     return b;
 }
 
@@ -238,48 +246,37 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
 template <int U, bool FAST>
 __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx)[U], const float (&ry)[U],
                                             const float (&r2)[U], float pres_i, float vix, float viy,
-                                            const float4 (&aj)[U] /* vx, vy, rho, P of j */, float (&fx)[U],
+                                            const float4 (&aj)[U] /* vx, vy, rho, P of j */,
+                                            const float (&yd)[U] /* FAST: refined 1 / rho_j */, float (&fx)[U],
                                             float (&fy)[U]) {
     float r_len[U], gcoeff[U], pt[U], visc[U], inv_r[U], lcoeff[U];
     if (FAST) {
-        // r2 below SPH_SQRT_LO (pairs closer than 1e-9, or denormal r2) is outside the validated range
-        // of sph_sqrt_exact: such a group takes the generic sqrtf (wave-uniform, practically never)
-        bool tiny = false;
+        // r2 is clamped to SPH_SQRT_LO = 2^-60 from below, i.e. r_len to 2^-30, for the rsq-based square
+        // root (no zero / denormal handling).  That changes nothing downstream: any r_len <= 1e-6 has its
+        // gradient and LJ terms zeroed by the guards below, and h - r_len == h for every r_len <= 2^-30
+        // because h >= 2^-5 (checked when fast_div is enabled, ctx.hip).  The divisions by such an r_len
+        // may produce inf / NaN: those feed only the two guarded coefficients.
+        float yr[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) tiny = tiny || (r2[u] < SPH_SQRT_LO && r2[u] != 0.0f);
-        if (__any(tiny)) {
+        for (int u = 0; u < U; u++) r_len[u] = sph_sqrt_core(fmaxf(r2[u], SPH_SQRT_LO), yr[u]);  // sph.cpp:67
 #pragma unroll
-            for (int u = 0; u < U; u++) r_len[u] = sqrtf(r2[u]);  // sph.cpp:67
-        } else {
+        for (int u = 0; u < U; u++) inv_r[u] = sph_div_core(1.0f, r_len[u], yr[u]);  // 1.0f / r_len, sph.cpp:31
 #pragma unroll
-            for (int u = 0; u < U; u++) r_len[u] = sph_sqrt_exact(r2[u]);  // sph.cpp:67
+        for (int u = 0; u < U; u++) {
+            float term = c.h - r_len[u];
+            gcoeff[u] = sph_div_core(c.spiky * term * term, r_len[u], yr[u]);  // sph.cpp:17-18
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)  // (P_i + P_j) / (2 rho_j) == ((P_i + P_j) / rho_j) / 2 exactly in the safe range;
+            pt[u] = sph_div_core(pres_i + aj[u].w, aj[u].z, yd[u]);  // the 1/2 is folded into neg_mass below, sph.cpp:69
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float lap = c.visc_lap * (c.h - r_len[u]);               // sph.cpp:23-26, see note (*)
+            visc[u] = sph_div_core(c.visc_mass * lap, aj[u].z, yd[u]);  // sph.cpp:72
         }
     } else {
 #pragma unroll
         for (int u = 0; u < U; u++) r_len[u] = sqrtf(r2[u]);  // sph.cpp:67
-    }
-    if (FAST) {
-        float yr[U], yd[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) yr[u] = sph_rcp_refined(r_len[u]);
-#pragma unroll
-        for (int u = 0; u < U; u++) yd[u] = sph_rcp_refined(aj[u].z);
-#pragma unroll
-        for (int u = 0; u < U; u++) inv_r[u] = sph_rcp_exact(r_len[u], yr[u]);  // 1.0f / r_len, sph.cpp:31
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            float term = c.h - r_len[u];
-            gcoeff[u] = sph_div_with_rcp(c.spiky * term * term, r_len[u], yr[u]);  // sph.cpp:17-18
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++)  // (P_i + P_j) / (2 rho_j) == ((P_i + P_j) / rho_j) / 2 exactly in the safe range
-            pt[u] = 0.5f * sph_div_with_rcp(pres_i + aj[u].w, aj[u].z, yd[u]);  // sph.cpp:69
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            float lap = c.visc_lap * (c.h - r_len[u]);                      // sph.cpp:23-26, see note (*)
-            visc[u] = sph_div_with_rcp(c.visc_mass * lap, aj[u].z, yd[u]);  // sph.cpp:72
-        }
-    } else {
 #pragma unroll
         for (int u = 0; u < U; u++) inv_r[u] = 1.0f / r_len[u];  // sph.cpp:31
 #pragma unroll
@@ -316,8 +313,11 @@ __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx
         float gc = zero_grad ? 0.0f : gcoeff[u];
         float gx = gc * rx[u];
         float gy = gc * ry[u];
-        float pfx = c.neg_mass * pt[u] * gx;  // sph.cpp:70
-        float pfy = c.neg_mass * pt[u] * gy;
+        // FAST: pt lacks its factor 1/2; (neg_mass / 2) * pt == neg_mass * (pt / 2) exactly (power of two,
+        // no underflow in the safe range)
+        const float nm = FAST ? 0.5f * c.neg_mass : c.neg_mass;
+        float pfx = nm * pt[u] * gx;  // sph.cpp:70
+        float pfy = nm * pt[u] * gy;
         float relx = aj[u].x - vix, rely = aj[u].y - viy;  // sph.cpp:71
         bool zero_lj = (r_len[u] >= c.lj_cut) || (r_len[u] < 1e-6f);  // sph.cpp:30
         float lc = zero_lj ? 0.0f : lcoeff[u];
@@ -330,9 +330,9 @@ __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx
 
 __device__ __forceinline__ void force_term(const DevConsts& c, float rx, float ry, float r2, float pres_i,
                                            float vix, float viy, float4 aj, float& fx, float& fy) {
-    float a[1] = {rx}, b[1] = {ry}, d[1] = {r2}, ox[1], oy[1];
+    float a[1] = {rx}, b[1] = {ry}, d[1] = {r2}, ox[1], oy[1], yd[1] = {0.0f};
     float4 e[1] = {aj};
-    force_terms<1, false>(c, a, b, d, pres_i, vix, viy, e, ox, oy);
+    force_terms<1, false>(c, a, b, d, pres_i, vix, viy, e, yd, ox, oy);
     fx = ox[0];
     fy = oy[0];
 }
@@ -401,7 +401,7 @@ __device__ __forceinline__ void integrate_one(const DevConsts& c, float2& p, flo
 // Heavy phase of one round: evaluates the qn queued pairs of every lane (byte offsets from `lo` in
 // s_q), FORCE_HEAVY_UNROLL at a time, in queue order.
 template <int THREADS, bool FAST>
-__device__ __forceinline__ void force_heavy(const DevConsts& c, const float2* s_pos, const float4* s_aux,
+__device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s_rec,
                                             uint8_t* s_q, int qn, int lo, int self_off, float2 pi, float2 vi,
                                             float pres_i, float& fx, float& fy) {
     const int tid = threadIdx.x;
@@ -412,6 +412,7 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const float2* s_
         float tx[FORCE_HEAVY_UNROLL], ty[FORCE_HEAVY_UNROLL];
         float rx[FORCE_HEAVY_UNROLL], ry[FORCE_HEAVY_UNROLL], r2[FORCE_HEAVY_UNROLL];
         float4 aj[FORCE_HEAVY_UNROLL];
+        float yd[FORCE_HEAVY_UNROLL];
 #pragma unroll
         for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
             int e = s_q[(t + u) * THREADS + tid];
@@ -419,13 +420,15 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const float2* s_
         }
 #pragma unroll
         for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
-            float2 q = s_pos[jj[u]];
-            aj[u] = s_aux[jj[u]];
+            const float4* rec = reinterpret_cast<const float4*>(s_rec + jj[u]);
+            aj[u] = rec[0];
+            const float4 q = rec[1];  // pos.x, pos.y, yd
+            yd[u] = q.z;
             rx[u] = pi.x - q.x;
             ry[u] = pi.y - q.y;
             r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
         }
-        force_terms<FORCE_HEAVY_UNROLL, FAST>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, tx, ty);
+        force_terms<FORCE_HEAVY_UNROLL, FAST>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, yd, tx, ty);
         // same order as the sequential sum: force += term(t); force += term(t+1); ...
 #pragma unroll
         for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
@@ -453,7 +456,7 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const float2* s_
 // and the queue tail is padded with the particle itself, so the accumulation needs no predicate.
 // !FAST keeps the reference's `j == i` test (sph.cpp:63) and a predicated accumulation.
 template <int THREADS, bool FAST>
-__device__ __forceinline__ void force_rounds(const DevConsts& c, const float2* s_pos, const float4* s_aux,
+__device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* s_rec,
                                              uint8_t* s_q, int j, int hi, int self, float2 pi, float2 vi,
                                              float pres_i, float& fx, float& fy) {
     const int tid = threadIdx.x;
@@ -466,7 +469,7 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const float2* s
             if ((j < hi) && (qn < FORCE_Q)) {
                 float2 q[FORCE_SCAN_UNROLL];
 #pragma unroll
-                for (int u = 0; u < FORCE_SCAN_UNROLL; u++) q[u] = s_pos[j + u];  // may run into the row sentinels
+                for (int u = 0; u < FORCE_SCAN_UNROLL; u++) q[u] = s_rec[j + u].pos;  // may run into the row sentinels
 #pragma unroll
                 for (int u = 0; u < FORCE_SCAN_UNROLL; u++) {
                     float rx = pi.x - q[u].x, ry = pi.y - q[u].y;
@@ -480,41 +483,57 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const float2* s
                 j += FORCE_SCAN_UNROLL;
             }
         }
-        force_heavy<THREADS, FAST>(c, s_pos, s_aux, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy);
+        force_heavy<THREADS, FAST>(c, s_rec, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy);
     }
 }
 
-// The same rounds with the scan replaced by the in-range bit masks k_density left behind (one word per
-// 32 candidates of the lane's range, first candidate in the top bit): a round pops up to FORCE_Q set
-// bits per lane into the queue, one per trip, refilling the current word from global memory (the next
-// word is fetched one refill ahead).  Only for FAST tiles: the masks contain the particle itself.
+// The neighbour sum driven by the in-range bit masks k_density left behind (one word per 32 candidates
+// of the lane's range, first candidate in the top bit) instead of a distance scan: every trip pops the
+// next FORCE_HEAVY_UNROLL set bits of every lane and evaluates those pairs.  The current word is
+// refilled from global memory (the next word is fetched one refill ahead); a lane that finds an empty
+// word, or has run out, evaluates itself for that slot -- a term of exactly +0 (see FAST above).
+// Only for FAST tiles: the masks contain the particle itself.
 template <int THREADS>
-__device__ __forceinline__ void force_rounds_mask(const DevConsts& c, const float2* s_pos, const float4* s_aux,
-                                                  uint8_t* s_q, const uint32_t* __restrict__ mask_col, int n_max,
-                                                  int lo, int nw, int self, float2 pi, float2 vi, float pres_i,
-                                                  float& fx, float& fy) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec* s_rec,
+                                              const uint32_t* __restrict__ mask_col, int n_max, int lo, int nw,
+                                              int self, float2 pi, float2 vi, float pres_i, float& fx, float& fy) {
+    constexpr int U = FORCE_HEAVY_UNROLL;
     const int self_off = self - lo;
     int w = 0;
     uint32_t m = 0, m_next = 0;
     if (nw > 0) m = mask_col[0];
     if (nw > 1) m_next = mask_col[(size_t)n_max];
     while (__any(m != 0 || w + 1 < nw)) {
-        int qn = 0;
-        while (__any((m != 0 || w + 1 < nw) && qn < FORCE_Q)) {
-            if ((m != 0 || w + 1 < nw) && qn < FORCE_Q) {
-                if (m == 0) {
-                    w++;
-                    m = m_next;
-                    if (w + 1 < nw) m_next = mask_col[(size_t)(w + 1) * n_max];
-                }
-                const int b = __clz((int)m) & 31;  // m == 0 (an empty word): nothing is pushed
-                s_q[qn * THREADS + tid] = (uint8_t)(32 * w + b);
-                qn += (m != 0) ? 1 : 0;
-                m &= 0x7fffffffu >> b;
+        int jj[U];
+        float tx[U], ty[U], rx[U], ry[U], r2[U], yd[U];
+        float4 aj[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (m == 0 && w + 1 < nw) {
+                w++;
+                m = m_next;
+                if (w + 1 < nw) m_next = mask_col[(size_t)(w + 1) * n_max];
             }
+            const int b = __clz((int)m) & 31;
+            jj[u] = lo + ((m != 0) ? 32 * w + b : self_off);
+            m &= 0x7fffffffu >> b;
         }
-        force_heavy<THREADS, true>(c, s_pos, s_aux, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float4* rec = reinterpret_cast<const float4*>(s_rec + jj[u]);
+            aj[u] = rec[0];
+            const float4 q = rec[1];  // pos.x, pos.y, yd
+            yd[u] = q.z;
+            rx[u] = pi.x - q.x;
+            ry[u] = pi.y - q.y;
+            r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
+        }
+        force_terms<U, true>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, yd, tx, ty);
+#pragma unroll
+        for (int u = 0; u < U; u++) {  // same order as the sequential sum
+            fx += tx[u];
+            fy += ty[u];
+        }
     }
 }
 
@@ -535,9 +554,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
                                                          float strength, int allow_fast,
                                                          const uint32_t* __restrict__ nmask, int n_max) {
     extern __shared__ __align__(16) float4 s_dyn[];
-    float4* s_aux = s_dyn;
-    float2* s_pos = reinterpret_cast<float2*>(s_dyn + cap);
-    int* s_off = reinterpret_cast<int*>(s_pos + cap);
+    PairRec* s_rec = reinterpret_cast<PairRec*>(s_dyn);
+    int* s_off = reinterpret_cast<int*>(s_rec + cap);
     int* s_gs = s_off + PAIR_MAXC + 1;
     int* s_wave = s_gs + PAIR_MAXC;
     uint8_t* s_q = reinterpret_cast<uint8_t*>(s_wave + 4);
@@ -585,14 +603,22 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
                 // r2 = +inf >= H*H skips it with the same compare that skips far particles.
                 no_mask |= (!(fabsf(q.x) < inf) || !(fabsf(q.y) < inf) || (idv[j] & SPH_INVALID_BIT)) ? 1 : 0;
                 if (idv[j] & SPH_INVALID_BIT) q = make_float2(inf, inf);
-                s_pos[o + k] = q;
-                s_aux[o + k] = make_float4(w.x, w.y, dj, pj);
+                PairRec rec;
+                rec.aux = make_float4(w.x, w.y, dj, pj);
+                rec.pos = q;
+                rec.yd = sph_rcp_refined(dj);
+                rec.pad = 0.0f;
+                s_rec[o + k] = rec;
             }
         }
         for (int t = threadIdx.x; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS) {
             int idx = s_off[3 * (t / PAIR_ROW_PAD) + 3] - PAIR_ROW_PAD + (t % PAIR_ROW_PAD);
-            s_pos[idx] = make_float2(inf, inf);
-            s_aux[idx] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+            PairRec rec;
+            rec.aux = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+            rec.pos = make_float2(inf, inf);
+            rec.yd = 1.0f;
+            rec.pad = 0.0f;
+            s_rec[idx] = rec;
         }
         fast = !__syncthreads_or(unsafe);
         by_mask = !__syncthreads_or(no_mask) && fast;
@@ -628,12 +654,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
                 self = s_off[self_cell] + (s - s_gs[self_cell]);
             }
             if (by_mask)
-                force_rounds_mask<THREADS>(c, s_pos, s_aux, s_q, nmask + (have ? s : 0), n_max, j, (hi - j + 31) >> 5,
-                                           self, pi, vi, pres_i, fx, fy);
+                force_by_mask<THREADS>(c, s_rec, nmask + (have ? s : 0), n_max, j, (hi - j + 31) >> 5, self, pi,
+                                       vi, pres_i, fx, fy);
             else if (fast)
-                force_rounds<THREADS, true>(c, s_pos, s_aux, s_q, j, hi, self, pi, vi, pres_i, fx, fy);
+                force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy);
             else
-                force_rounds<THREADS, false>(c, s_pos, s_aux, s_q, j, hi, self, pi, vi, pres_i, fx, fy);
+                force_rounds<THREADS, false>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy);
         } else if (have && valid) {
             for (int cc = 3 * r0; cc < 3 * r1 + 3; cc++) {
                 int gs = s_gs[cc], n = cand_count(s_off, cc);

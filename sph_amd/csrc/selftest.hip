@@ -19,7 +19,7 @@ __global__ void k_check_rcp(unsigned lo_bits, unsigned hi_bits, unsigned long lo
         for (int sgn = 0; sgn < 2; sgn++) {
             float x = __uint_as_float((unsigned)b | (sgn ? 0x80000000u : 0u));
             float want = 1.0f / x;
-            float got = sph_rcp_exact(x, sph_rcp_refined(x));
+            float got = sph_div_core(1.0f, x, sph_rcp_refined(x));  // as k_force uses it: no special-case fixup
             nbad += (__float_as_uint(want) != __float_as_uint(got)) ? 1 : 0;
         }
     }
@@ -59,10 +59,10 @@ __global__ void k_check_div(unsigned long long n, int mode, unsigned long long s
         float want, got;
         if (mode == 2) {
             want = a / (2.0f * b);
-            got = 0.5f * sph_div_with_rcp(a, b, y);
+            got = 0.5f * sph_div_core(a, b, y);
         } else {
             want = a / b;
-            got = sph_div_with_rcp(a, b, y);
+            got = mode == 3 ? sph_div_with_rcp(a, b, y) : sph_div_core(a, b, y);
         }
         bool same = (__float_as_uint(want) == __float_as_uint(got)) || (want != want && got != got);
         nbad += same ? 0 : 1;
@@ -77,13 +77,16 @@ __global__ void k_check_sqrt(unsigned lo_bits, unsigned hi_bits, unsigned long l
     unsigned long long nbad = 0;
     for (unsigned long long b = lo_bits + i; b <= hi_bits; b += stride) {
         float x = __uint_as_float((unsigned)b);
-        float s = sph_sqrt_exact(x);
-        float y = sph_rcp_refined(s);
+        float y;
+        float s = x == 0.0f ? sph_sqrt_exact(x) : sph_sqrt_core(x, y);  // y: the reciprocal k_force divides with
+        if (x == 0.0f) y = sph_rcp_refined(s);
         float want = sqrtf(x);
         bool ok = __float_as_uint(want) == __float_as_uint(s);
         float a = rnd_safe(splitmix(b), -30, 24);
-        ok = ok && (__float_as_uint(1.0f / want) == __float_as_uint(sph_div_with_rcp(1.0f, s, y)));
-        ok = ok && (__float_as_uint(a / want) == __float_as_uint(sph_div_with_rcp(a, s, y)));
+        if (x != 0.0f) {
+            ok = ok && (__float_as_uint(1.0f / want) == __float_as_uint(sph_div_core(1.0f, s, y)));
+            ok = ok && (__float_as_uint(a / want) == __float_as_uint(sph_div_core(a, s, y)));
+        }
         nbad += ok ? 0 : 1;
     }
     if (nbad) atomicAdd(bad, nbad);
