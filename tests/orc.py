@@ -202,3 +202,16 @@ def bits(a):
 
 def same_bits(a, b):
     return np.array_equal(bits(a), bits(b))
+
+
+def same_bits_nan(a, b):
+    """same_bits, except that a NaN matches a NaN whatever its sign and payload (x86 produces the
+    negative default NaN, gfx950 the positive one)."""
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if len(a) != len(b) or not np.array_equal(a["valid"], b["valid"]):
+        return False
+    fa = a.view(np.uint8).reshape(len(a), 28)[:, :24].copy().view(np.float32)
+    fb = b.view(np.uint8).reshape(len(b), 28)[:, :24].copy().view(np.float32)
+    both_nan = np.isnan(fa) & np.isnan(fb)
+    return bool(np.all((fa.view(np.uint32) == fb.view(np.uint32)) | both_nan))
