@@ -192,6 +192,7 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
         if (const char* e = getenv("SPHHIP_FAST_DIV")) c->fast_div = c->fast_div && atoi(e) != 0;
     }
     if (const char* e = getenv("SPHHIP_USE_MASKS")) c->use_masks = atoi(e) != 0;
+    if (const char* e = getenv("SPHHIP_GRID")) c->grid_counting = std::string(e) != "radix";
     if (const char* e = getenv("SPHHIP_PAIR_THREADS")) {
         int v = atoi(e);
         if (v == 128 || v == 256) c->pair_threads = v;

@@ -330,6 +330,132 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Counting sort by cell (the default grid build).  The radix sort above orders (key, slot) pairs in
+// three or four passes; but nothing downstream needs the slot order inside a cell -- k_rank_reorder
+// ranks cell-mates by id anyway -- so one counting pass is enough:
+//   k_cell_count    key per particle + its arrival index within the cell (atomic counter per cell;
+//                   a run of equal keys in a wave -- the common case, the state is still in last
+//                   step's cell order -- is counted by one atomic of its head lane)
+//   k_scan_*        exclusive prefix sum of the counts -> cell_start (monotone, ncell + 1 entries)
+//   k_cell_scatter  sorted slot = cell_start[key] + arrival index: keys / source slot / id per slot
+// The arrival order is not deterministic; the (key, id) order after k_rank_reorder is.
+// R pos 8, W key 4 + rank 4; scan 2 x 8 B per cell; scatter R 12, W 12 per particle.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cell_count(DevConsts c, const float2* __restrict__ pos,
+                                                     const int* __restrict__ d_n, uint32_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ rank, int* __restrict__ cell_cnt) {
+    const int n = *d_n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < n;
+    uint32_t key = 0xffffffffu;
+    if (ok) {
+        float2 p = pos[i];
+        int cx = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
+        int cy = sph_cell_coord(p.y, c.ymin, c.inv_cell, c.ny);
+        key = (uint32_t)(cx * c.ny + cy);
+    }
+    const int lane = sph_lane_id();
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool head = ok && (lane == 0 || prev != key);
+    const unsigned long long heads = __ballot(head);
+    const int n_ok = __popcll(__ballot(ok));  // the in-range lanes are a prefix of the wave
+    const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);  // lanes 0..lane
+    const unsigned long long below = heads & upto;
+    const int start = below ? 63 - __clzll((long long)below) : 0;  // head lane of this lane's run
+    int base = 0;
+    if (head) {
+        const unsigned long long above = heads & ~upto;
+        const int next = above ? __ffsll((long long)above) - 1 : n_ok;
+        base = atomicAdd(&cell_cnt[key], next - lane);
+    }
+    base = __shfl(base, start, 64);
+    if (ok) {
+        keys[i] = key;
+        rank[i] = (uint32_t)(base + lane - start);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t* __restrict__ keys,
+                                                       const uint32_t* __restrict__ rank,
+                                                       const uint32_t* __restrict__ idv, const int* __restrict__ d_n,
+                                                       const int* __restrict__ cell_start,
+                                                       uint32_t* __restrict__ skeys, uint32_t* __restrict__ perm,
+                                                       uint32_t* __restrict__ ids_sorted) {
+    const int n = *d_n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    const int slot = cell_start[k] + (int)rank[i];
+    skeys[slot] = k;
+    perm[slot] = (uint32_t)i;
+    ids_sorted[slot] = idv[i] & SPH_ID_MASK;
+}
+
+// Exclusive prefix sum over len ints in place, chunks of SCAN_CHUNK: chunk sums, then every chunk adds
+// the sums of the chunks before it (summed by the workgroup itself: at most a few thousand values).
+__global__ __launch_bounds__(256) void k_scan_reduce(const int* __restrict__ a, int len, int* __restrict__ part) {
+    __shared__ int w[4];
+    const int base = blockIdx.x * SCAN_CHUNK;
+    int sum = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_CHUNK / 256; r++) {
+        int i = base + r * 256 + (int)threadIdx.x;
+        if (i < len) sum += a[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ a, int len, const int* __restrict__ part) {
+    __shared__ int buf[SCAN_CHUNK];
+    __shared__ int wsum[4];
+    __shared__ int wtot[4];
+    const int base = blockIdx.x * SCAN_CHUNK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int before = 0;  // sum of the chunks before this one
+    for (int b = tid; b < (int)blockIdx.x; b += 256) before += part[b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
+    if (lane == 0) wsum[wave] = before;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int i = base + r * 256 + tid;  // coalesced load into LDS
+        buf[r * 256 + tid] = (i < len) ? a[i] : 0;
+    }
+    __syncthreads();
+    before = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // thread t owns the 8 consecutive cells base + 8t .. base + 8t + 7
+    int v[8];
+    int run = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        v[r] = run;
+        run += buf[tid * 8 + r];
+    }
+    int incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int off = before + incl - run;
+    for (int w = 0; w < wave; w++) off += wtot[w];
+#pragma unroll
+    for (int r = 0; r < 8; r++) buf[tid * 8 + r] = v[r] + off;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int i = base + r * 256 + tid;
+        if (i < len) a[i] = buf[r * 256 + tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 static inline int ilog2_ceil(unsigned v) {
     int b = 0;
     while ((1u << b) < v && b < 31) b++;
@@ -340,50 +466,76 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     const int n = sph_n_grid(c);  // exact count, or the capacity while the count is only known on the device
     hipStream_t st = c->stream;
     const int ncell = c->ncell;
-    if (n > 0) {
+    if (c->grid_counting) {
+        const int len = ncell + 1;
+        const int nparts = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
         {
             PhaseScope ps(c, SPHHIP_PH_HASH);
-            hipLaunchKernelGGL(k_hash, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, c->d_n, c->keys, c->perm);
-            LAUNCH_CHECK();
-        }
-        {
-            PhaseScope ps(c, SPHHIP_PH_SORT);
-            int key_bits = ilog2_ceil((unsigned)ncell);
-            if (key_bits < 1) key_bits = 1;
-            int passes = (key_bits + 7) / 8;
-            int bits_per_pass = (key_bits + passes - 1) / passes;
-            int nblocks = (n + SORT_TILE - 1) / SORT_TILE;
-            int shift = 0;
-            for (int p = 0; p < passes; p++) {
-                int bits = min(bits_per_pass, key_bits - shift);
-                uint32_t mask = (1u << bits) - 1u;
-                hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(SORT_THREADS), 0, st, c->keys, c->d_n, shift, mask,
-                                   c->block_hist, nblocks);
-                hipLaunchKernelGGL(k_sort_scan_rows, dim3(SORT_RADIX), dim3(256), 0, st, c->block_hist, nblocks,
-                                   c->digit_total);
-                hipLaunchKernelGGL(k_sort_scan_digits, dim3(1), dim3(256), 0, st, c->digit_total);
-                hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(SORT_THREADS), 0, st, c->keys, c->perm,
-                                   c->keys2, c->perm2, c->d_n, shift, mask, c->block_hist, c->digit_total, nblocks);
+            HIP_TRY(hipMemsetAsync(c->cell_start, 0, sizeof(int) * (size_t)len, st));
+            if (n > 0) {
+                hipLaunchKernelGGL(k_cell_count, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, c->d_n, c->keys2,
+                                   c->perm2, c->cell_start);
                 LAUNCH_CHECK();
-                std::swap(c->keys, c->keys2);
-                std::swap(c->perm, c->perm2);
-                shift += bits;
             }
         }
-    }
-    {
-        PhaseScope ps(c, SPHHIP_PH_CELLS);
-        const int len = ncell + 1;
-        HIP_TRY(hipMemsetAsync(c->cell_start, 0x7f, sizeof(int) * (size_t)len, st));
-        if (n > 0) {
-            hipLaunchKernelGGL(k_cell_marks, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm, c->idv, c->d_n,
-                               c->cell_start, c->ids_sorted);
+        {
+            PhaseScope ps(c, SPHHIP_PH_CELLS);
+            hipLaunchKernelGGL(k_scan_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp);
+            hipLaunchKernelGGL(k_scan_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp);
+            LAUNCH_CHECK();
         }
-        int nparts = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        hipLaunchKernelGGL(k_sufmin_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp);
-        hipLaunchKernelGGL(k_sufmin_parts, dim3(1), dim3(256), 0, st, c->scan_tmp, nparts);
-        hipLaunchKernelGGL(k_sufmin_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp, c->d_n);
-        LAUNCH_CHECK();
+        if (n > 0) {
+            PhaseScope ps(c, SPHHIP_PH_SORT);
+            hipLaunchKernelGGL(k_cell_scatter, dim3((n + 255) / 256), dim3(256), 0, st, c->keys2, c->perm2, c->idv, c->d_n,
+                               c->cell_start, c->keys, c->perm, c->ids_sorted);
+            LAUNCH_CHECK();
+        }
+    } else {
+        if (n > 0) {
+            {
+                PhaseScope ps(c, SPHHIP_PH_HASH);
+                hipLaunchKernelGGL(k_hash, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, c->d_n, c->keys, c->perm);
+                LAUNCH_CHECK();
+            }
+            {
+                PhaseScope ps(c, SPHHIP_PH_SORT);
+                int key_bits = ilog2_ceil((unsigned)ncell);
+                if (key_bits < 1) key_bits = 1;
+                int passes = (key_bits + 7) / 8;
+                int bits_per_pass = (key_bits + passes - 1) / passes;
+                int nblocks = (n + SORT_TILE - 1) / SORT_TILE;
+                int shift = 0;
+                for (int p = 0; p < passes; p++) {
+                    int bits = min(bits_per_pass, key_bits - shift);
+                    uint32_t mask = (1u << bits) - 1u;
+                    hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(SORT_THREADS), 0, st, c->keys, c->d_n, shift, mask,
+                                       c->block_hist, nblocks);
+                    hipLaunchKernelGGL(k_sort_scan_rows, dim3(SORT_RADIX), dim3(256), 0, st, c->block_hist, nblocks,
+                                       c->digit_total);
+                    hipLaunchKernelGGL(k_sort_scan_digits, dim3(1), dim3(256), 0, st, c->digit_total);
+                    hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(SORT_THREADS), 0, st, c->keys, c->perm,
+                                       c->keys2, c->perm2, c->d_n, shift, mask, c->block_hist, c->digit_total, nblocks);
+                    LAUNCH_CHECK();
+                    std::swap(c->keys, c->keys2);
+                    std::swap(c->perm, c->perm2);
+                    shift += bits;
+                }
+            }
+        }
+        {
+            PhaseScope ps(c, SPHHIP_PH_CELLS);
+            const int len = ncell + 1;
+            HIP_TRY(hipMemsetAsync(c->cell_start, 0x7f, sizeof(int) * (size_t)len, st));
+            if (n > 0) {
+                hipLaunchKernelGGL(k_cell_marks, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm, c->idv, c->d_n,
+                                   c->cell_start, c->ids_sorted);
+            }
+            int nparts = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
+            hipLaunchKernelGGL(k_sufmin_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp);
+            hipLaunchKernelGGL(k_sufmin_parts, dim3(1), dim3(256), 0, st, c->scan_tmp, nparts);
+            hipLaunchKernelGGL(k_sufmin_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp, c->d_n);
+            LAUNCH_CHECK();
+        }
     }
     if (n > 0) {
         PhaseScope ps(c, SPHHIP_PH_REORDER);

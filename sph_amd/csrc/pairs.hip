@@ -66,7 +66,9 @@ struct TileGeom {
 
 static size_t pair_lds_bytes(int cap, bool force, int threads) {
     size_t b = sizeof(int) * (2 * PAIR_MAXC + 1 + 4);
-    b += force ? sizeof(PairRec) * (size_t)cap + sizeof(uint8_t) * FORCE_QCAP * threads : sizeof(float2) * (size_t)cap;
+    // (the scan path's byte queue and the mask path's mask words share one region)
+    const size_t qbytes = sizeof(uint8_t) * FORCE_QCAP * threads, mbytes = sizeof(uint32_t) * PAIR_MASK_WORDS * threads;
+    b += force ? sizeof(PairRec) * (size_t)cap + (qbytes > mbytes ? qbytes : mbytes) : sizeof(float2) * (size_t)cap;
     return b;
 }
 
@@ -493,47 +495,85 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* 
 // refilled from global memory (the next word is fetched one refill ahead); a lane that finds an empty
 // word, or has run out, evaluates itself for that slot -- a term of exactly +0 (see FAST above).
 // Only for FAST tiles: the masks contain the particle itself.
+// One group of FORCE_HEAVY_UNROLL queued pairs as raw LDS records (nothing computed on them yet, so the
+// reads can stay in flight while the previous group is evaluated).
+struct PairGroup {
+    float4 aux[FORCE_HEAVY_UNROLL];  // vx, vy, rho, P
+    float4 pq[FORCE_HEAVY_UNROLL];   // pos.x, pos.y, yd, -
+};
+
 template <int THREADS>
-__device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec* s_rec,
+__device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec* s_rec, uint32_t* s_mask,
                                               const uint32_t* __restrict__ mask_col, int n_max, int lo, int nw,
                                               int self, float2 pi, float2 vi, float pres_i, float& fx, float& fy) {
     constexpr int U = FORCE_HEAVY_UNROLL;
-    const int self_off = self - lo;
+    const int tid = threadIdx.x;
+    // The lane's mask words go to LDS first (s_mask[w * THREADS + tid]; one batch of coalesced global
+    // loads): the refills inside the pop loop are divergent, and a global load there would stall the
+    // wave for a full memory round trip at almost every pop.
+#pragma unroll
+    for (int k = 0; k < PAIR_MASK_WORDS; k++)
+        if (k < nw) s_mask[k * THREADS + tid] = mask_col[(size_t)k * n_max];
     int w = 0;
+    int base = lo;  // LDS index of the candidate in bit 31 of the current word
     uint32_t m = 0, m_next = 0;
-    if (nw > 0) m = mask_col[0];
-    if (nw > 1) m_next = mask_col[(size_t)n_max];
-    while (__any(m != 0 || w + 1 < nw)) {
-        int jj[U];
-        float tx[U], ty[U], rx[U], ry[U], r2[U], yd[U];
-        float4 aj[U];
+    if (nw > 0) m = s_mask[tid];
+    if (nw > 1) m_next = s_mask[THREADS + tid];
+#if defined(FORCE_EXPERIMENT) && FORCE_EXPERIMENT == 2
+    nw = 0; m = 0;
+#endif
+    // pops the next U set bits of the lane and starts the LDS reads of those records
+    auto fetch = [&](PairGroup& g) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (m == 0 && w + 1 < nw) {
                 w++;
+                base += 32;
                 m = m_next;
-                if (w + 1 < nw) m_next = mask_col[(size_t)(w + 1) * n_max];
+                if (w + 1 < nw) m_next = s_mask[(w + 1) * THREADS + tid];
             }
-            const int b = __clz((int)m) & 31;
-            jj[u] = lo + ((m != 0) ? 32 * w + b : self_off);
+            const int b = __builtin_clz(m | 1u);  // (m == 0: any value, the slot evaluates the particle itself)
+            const int jj = (m != 0) ? base + b : self;
             m &= 0x7fffffffu >> b;
+            const float4* rec = reinterpret_cast<const float4*>(s_rec + jj);
+            g.aux[u] = rec[0];
+            g.pq[u] = rec[1];
         }
+    };
+    auto eval = [&](const PairGroup& g) {
+        float tx[U], ty[U], rx[U], ry[U], r2[U], yd[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const float4* rec = reinterpret_cast<const float4*>(s_rec + jj[u]);
-            aj[u] = rec[0];
-            const float4 q = rec[1];  // pos.x, pos.y, yd
-            yd[u] = q.z;
-            rx[u] = pi.x - q.x;
-            ry[u] = pi.y - q.y;
+            yd[u] = g.pq[u].z;
+            rx[u] = pi.x - g.pq[u].x;
+            ry[u] = pi.y - g.pq[u].y;
             r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
         }
-        force_terms<U, true>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, yd, tx, ty);
+#if defined(FORCE_EXPERIMENT) && FORCE_EXPERIMENT == 1
+        for (int u = 0; u < U; u++) { tx[u] = rx[u] * g.aux[u].x + yd[u]; ty[u] = ry[u] * g.aux[u].w + r2[u]; }
+#else
+        force_terms<U, true>(c, rx, ry, r2, pres_i, vi.x, vi.y, g.aux, yd, tx, ty);
+#endif
 #pragma unroll
         for (int u = 0; u < U; u++) {  // same order as the sequential sum
             fx += tx[u];
             fy += ty[u];
         }
+    };
+    // Software pipeline, two register sets: the bit pops and LDS reads of the next group are issued
+    // before the current group is evaluated.  `live`: some lane of the wave still had pairs when the
+    // group was fetched (a group fetched after that holds only self-pairs and is dropped).
+    PairGroup ga, gb;
+    bool live = __any(m != 0 || w + 1 < nw);
+    fetch(ga);
+    while (live) {
+        const bool live_b = __any(m != 0 || w + 1 < nw);
+        fetch(gb);
+        eval(ga);
+        if (!live_b) break;
+        live = __any(m != 0 || w + 1 < nw);
+        fetch(ga);
+        eval(gb);
     }
 }
 
@@ -654,7 +694,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
                 self = s_off[self_cell] + (s - s_gs[self_cell]);
             }
             if (by_mask)
-                force_by_mask<THREADS>(c, s_rec, nmask + (have ? s : 0), n_max, j, (hi - j + 31) >> 5, self, pi,
+                force_by_mask<THREADS>(c, s_rec, reinterpret_cast<uint32_t*>(s_q), nmask + (have ? s : 0), n_max, j, (hi - j + 31) >> 5, self, pi,
                                        vi, pres_i, fx, fy);
             else if (fast)
                 force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy);

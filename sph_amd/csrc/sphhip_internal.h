@@ -62,7 +62,7 @@ struct SphCtx {
     int slice_lo = 0, slice_hi = 0;
     int col_lo = 0, col_hi = 0;  // owned columns (default: all)
     int tile_cells = 12;         // cells of a column per pair-kernel workgroup
-    int pair_cap = 1024;
+    int pair_cap = 960;          // neighbour candidates staged in LDS per workgroup (4 workgroups of k_force per CU)
     int pair_threads = 256;      // 128 or 256
     bool fast_div = true;        // exact_div.h allowed (constants in its safe range; SPHHIP_FAST_DIV=0 disables)         // neighbour candidates staged in LDS per workgroup
 
@@ -73,6 +73,7 @@ struct SphCtx {
     int* ncount = nullptr;  // neighbour counts of the last density pass (slot order)
     uint32_t* nmask = nullptr;  // in-range bit masks of the last density pass: word w of slot s at [w * n_max + s]
     int mask_tile_cells = 0, mask_cap = 0;  // tiling the masks were built with
+    bool grid_counting = true;  // counting sort by cell (SPHHIP_GRID=radix: the LSD radix sort)
     bool use_masks = true;      // SPHHIP_USE_MASKS=0: k_force always scans
 
     // grid
