@@ -150,15 +150,21 @@ __device__ __forceinline__ void density_acc(const DevConsts& c, float2 pi, float
     cnt += in ? 1 : 0;
 }
 
-// same, with the in-range bit shifted into m (m = 2m + in: one add-with-carry) instead of a count
+// The same sum without a compare or select (those cost twice an fp32 add on gfx950), and with the
+// in-range bit shifted into m:
+//   t = r2 - h2 = -(h2 - r2) exactly, so max(-t, 0) is the reference's (h2 - r2) when r2 < h2 and +0
+//   otherwise (also for the +inf sentinels and for NaN); a term of mass * (poly6 * 0 * 0 * 0) = +0 leaves
+//   the sum unchanged, like the reference's skipped iteration;
+//   r2 < h2  <=>  t < 0  <=>  sign bit of t (t is never -0; for NaN positions the bit is unspecified --
+//   k_force does not use the masks of a tile that holds a non-finite position, and the neighbour count
+//   of such a scene is unspecified).
 __device__ __forceinline__ void density_acc_mask(const DevConsts& c, float2 pi, float2 q, float& dens, uint32_t& m) {
     float rx = pi.x - q.x, ry = pi.y - q.y;
     float r2 = rx * rx + ry * ry;
-    float term = c.h2 - r2;
-    float w = c.mass * (c.poly6 * term * term * term);
-    bool in = r2 < c.h2;
-    dens += in ? w : 0.0f;
-    m = m + m + (in ? 1u : 0u);
+    float t = r2 - c.h2;
+    float term = fmaxf(-t, 0.0f);
+    dens += c.mass * (c.poly6 * term * term * term);  // MASS * poly6(r2, H), sph.cpp:11,49
+    m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);  // (m << 1) | sign(t)
 }
 
 template <int THREADS>
