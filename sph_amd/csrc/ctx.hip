@@ -149,13 +149,14 @@ static hipError_t dmalloc(T** p, size_t count) {
 static void free_all(SphCtx* c) {
     void* ptrs[] = {c->pos, c->vel, c->pos2, c->vel2, c->rho, c->prs, c->rho2, c->prs2, c->idv, c->idv2,
                     c->ncount, c->nmask, c->keys, c->keys2, c->perm, c->perm2, c->ids_sorted, c->cell_start, c->block_hist,
-                    c->digit_total, c->scan_tmp, c->counters, c->staging};
+                    c->digit_total, c->scan_tmp, c->counters, c->tile_list, c->staging};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int ph = 0; ph < SPHHIP_PH_COUNT; ph++) {
         for (hipEvent_t e : c->timer.start[ph]) (void)hipEventDestroy(e);
         for (hipEvent_t e : c->timer.stop[ph]) (void)hipEventDestroy(e);
     }
+    if (c->h_host_tiles) (void)hipHostFree(c->h_host_tiles);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 }
 
@@ -218,6 +219,13 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     ok(dmalloc(&c->digit_total, 2 * SORT_RADIX));
     ok(dmalloc(&c->scan_tmp, (size_t)(c->ncell + 1 + 2047) / 2048 + 1));
     ok(dmalloc(&c->counters, 64));
+    ok(dmalloc(&c->tile_list, (size_t)c->ncell + c->ncell / 64 + 64));
+    ok(hipHostMalloc((void**)&c->h_host_tiles, sizeof(int), hipHostMallocMapped));
+    if (e == hipSuccess) {
+        *c->h_host_tiles = -1;
+        ok(hipHostGetDevicePointer((void**)&c->d_host_tiles, c->h_host_tiles, 0));
+    }
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->num_cus = v; }
     if (e == hipSuccess) ok(hipMemset(c->counters, 0, sizeof(int) * 64));
     c->d_err = c->counters + 16;
     c->n_ring = c->counters + 32;

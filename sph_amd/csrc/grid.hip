@@ -558,6 +558,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     }
     c->grid_valid = true;
     c->counts_valid = false;
+    c->tiles_valid = false;
     // when only part of the columns is owned, remember which slot range that is (ghost dropping)
     c->slice_valid = (c->col_lo > 0 || c->col_hi < c->dc.nx);
     c->slice_lo = c->col_lo;

@@ -31,7 +31,7 @@
 //
 // All LDS of the pair kernels is one dynamic array (16-byte aligned base, no static __shared__ in
 // front of it): [PairRec rec[cap]] (force) or [float2 pos[cap]] (density) [int off[MAXC+1]] [int gs[MAXC]]
-// [int wave_tmp[4]] [u8 queue[QCAP*256]] (force only).
+// [int wave_tmp[4]] [int tile[4]] [u8 queue[QCAP*256] | u32 masks[8*256]] (force only).
 // ---------------------------------------------------------------------------------------------
 constexpr int PAIR_MAXC = 3 * (PAIR_MAX_TILE_CELLS + 2);  // candidate cells of a tile (<= 256)
 #ifndef FORCE_Q
@@ -65,7 +65,7 @@ struct TileGeom {
 };
 
 static size_t pair_lds_bytes(int cap, bool force, int threads) {
-    size_t b = sizeof(int) * (2 * PAIR_MAXC + 1 + 4);
+    size_t b = sizeof(int) * (2 * PAIR_MAXC + 1 + 4 + 4);  // off, gs, wave_tmp, queue slot
     // (the scan path's byte queue and the mask path's mask words share one region)
     const size_t qbytes = sizeof(uint8_t) * FORCE_QCAP * threads, mbytes = sizeof(uint32_t) * PAIR_MASK_WORDS * threads;
     b += force ? sizeof(PairRec) * (size_t)cap + (qbytes > mbytes ? qbytes : mbytes) : sizeof(float2) * (size_t)cap;
@@ -74,8 +74,8 @@ static size_t pair_lds_bytes(int cap, bool force, int threads) {
 
 // Exclusive scan of one int per thread over the workgroup of THREADS threads (two barriers).
 template <int THREADS>
-__device__ __forceinline__ int wg_excl_scan(int v, int* lds_wave, int& total) {
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ int wg_excl_scan(int v, int* lds_wave, int& total, int tix) {
+    int lane = tix & 63, wave = tix >> 6;
     int incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -105,7 +105,7 @@ __device__ __forceinline__ int cand_count(const int* s_off, int cc) {  // real p
 
 template <int THREADS>
 __device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __restrict__ cell_start, int col, int trow,
-                                           int tile_cells, TileGeom& g, int* s_off, int* s_gs, int* s_wave) {
+                                           int tile_cells, TileGeom& g, int* s_off, int* s_gs, int* s_wave, int tix) {
     g.col = col;
     g.cy0 = trow * tile_cells;
     g.cy1 = min(g.cy0 + tile_cells, c.ny);
@@ -115,7 +115,7 @@ __device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __rest
     g.own_hi = cell_start[col * c.ny + g.cy1];
     if (g.own_lo == g.own_hi) return false;
     g.ncells = 3 * (g.yhi - g.ylo);
-    int t = threadIdx.x;
+    int t = tix;
     int cnt = 0, g0 = 0;
     if (t < g.ncells) {
         int row = t / 3, d = t - 3 * row;
@@ -127,7 +127,7 @@ __device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __rest
         }
     }
     int padded = cnt + ((t < g.ncells && (t % 3) == 2) ? PAIR_ROW_PAD : 0);
-    int ex = wg_excl_scan<THREADS>(padded, s_wave, g.total);
+    int ex = wg_excl_scan<THREADS>(padded, s_wave, g.total, tix);
     if (t < g.ncells) {
         s_off[t] = ex;
         s_gs[t] = g0;
@@ -167,37 +167,73 @@ __device__ __forceinline__ void density_acc_mask(const DevConsts& c, float2 pi, 
     m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);  // (m << 1) | sign(t)
 }
 
+// ---------------------------------------------------------------------------------------------
+// Work distribution of the pair kernels: a compacted list of the non-empty tiles.
+// ensure_tile_list (below) compacts the non-empty tiles of the launch range into `tile_list`
+// (tile id = col * tiles_per_col + trow, in band-major order: 4 adjacent columns, then rows) and
+// splits it into 8 contiguous chunks, one per XCD (workgroup b runs on XCD b % 8 under round-robin
+// dispatch): horizontally adjacent tiles -- which share two of their three candidate columns -- are
+// then served by the same XCD's L2.  A dam break fills an eighth of the grid: launching one workgroup
+// per tile of the whole grid spent a fifth of both pair kernels on empty workgroups.
+// The number of listed tiles is only known on the device.  The host sizes the grid from the count a
+// previous launch wrote into mapped host memory (one workgroup per tile, a little slack), or, while it
+// has none, for one resident wave of workgroups; workgroups stride over their chunk, so any grid size
+// is correct.  (Fully persistent workgroups were 20 % slower: they run in lock-step, every workgroup
+// in its latency-bound tile prologue at the same time.)
+// ---------------------------------------------------------------------------------------------
+struct TileQueue {
+    const int* list;   // compacted tile ids
+    const int* count;  // number of entries
+    int* host_count;   // mapped host memory: the count, for sizing later launches
+    int tiles_per_col;
+};
+
+// Workgroup b takes entry (b & 7) * gridDim/8 + (b >> 3), then strides by gridDim: chunk b & 7 of the
+// list goes to XCD b & 7.  The count and the first tile id are fetched together (wave-uniform loads);
+// the id of the next tile while the current one is processed.  `tix` is threadIdx.x behind an opaque
+// barrier: without it the compiler hoists ~20 VGPRs of thread-index arithmetic out of the (rarely
+// repeated) loop and the force kernel drops from 4 to 3 workgroups per CU.
+template <class Body>
+__device__ __forceinline__ void for_each_tile(const TileQueue& q, Body&& body) {
+    const int total = *q.count;
+    int t = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    int tile = q.list[t];  // (the list is allocated for every t a launch can produce)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *(volatile int*)q.host_count = total;
+    while (t < total) {
+        const int t_next = t + (int)gridDim.x;
+        const int tile_next = t_next < total ? q.list[t_next] : 0;
+        __syncthreads();  // the previous tile is done with the LDS image
+        int tix = threadIdx.x;
+        asm volatile("" : "+v"(tix));
+        body(tile / q.tiles_per_col, tile % q.tiles_per_col, tix);
+        t = t_next;
+        tile = tile_next;
+    }
+}
+
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* __restrict__ pos,
-                                                           const uint32_t* __restrict__ skeys,
-                                                           const int* __restrict__ cell_start,
-                                                           float* __restrict__ rho, float* __restrict__ prs,
-                                                           int* __restrict__ ncount, uint32_t* __restrict__ nmask,
-                                                           int n_max, int col0, int ncols, int tiles_per_col,
-                                                           int tile_cells, int cap) {
-    extern __shared__ __align__(16) float4 s_dyn[];
-    float2* s_pos = reinterpret_cast<float2*>(s_dyn);
-    int* s_off = reinterpret_cast<int*>(s_pos + cap);
-    int* s_gs = s_off + PAIR_MAXC + 1;
-    int* s_wave = s_gs + PAIR_MAXC;
-    int tcol, trow;
-    if (!sph_tile_of_block(blockIdx.x, ncols, tiles_per_col, tcol, trow)) return;
+__device__ __forceinline__ void density_tile(const DevConsts& c, const float2* __restrict__ pos,
+                                             const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
+                                             float* __restrict__ rho, float* __restrict__ prs,
+                                             int* __restrict__ ncount, uint32_t* __restrict__ nmask, int n_max,
+                                             int col, int trow, int tile_cells, int cap, float2* s_pos, int* s_off,
+                                             int* s_gs, int* s_wave, int tix) {
     TileGeom g;
-    if (!tile_setup<THREADS>(c, cell_start, col0 + tcol, trow, tile_cells, g, s_off, s_gs, s_wave)) return;
+    if (!tile_setup<THREADS>(c, cell_start, col, trow, tile_cells, g, s_off, s_gs, s_wave, tix)) return;
     __syncthreads();
     const bool use_lds = g.total <= cap;
     if (use_lds) {
         // 16 lanes per candidate cell, 16 cells per pass
-        for (int cc = threadIdx.x >> 4; cc < g.ncells; cc += THREADS / 16) {
+        for (int cc = tix >> 4; cc < g.ncells; cc += THREADS / 16) {
             int o = s_off[cc], n = cand_count(s_off, cc), gs = s_gs[cc];
-            for (int k = threadIdx.x & 15; k < n; k += 16) s_pos[o + k] = pos[gs + k];
+            for (int k = tix & 15; k < n; k += 16) s_pos[o + k] = pos[gs + k];
         }
-        for (int t = threadIdx.x; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS)
+        for (int t = tix; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS)
             s_pos[s_off[3 * (t / PAIR_ROW_PAD) + 3] - PAIR_ROW_PAD + (t % PAIR_ROW_PAD)] =
                 make_float2(__builtin_inff(), __builtin_inff());
         __syncthreads();
     }
-    for (int s = g.own_lo + (int)threadIdx.x; s < g.own_hi; s += THREADS) {
+    for (int s = g.own_lo + tix; s < g.own_hi; s += THREADS) {
         const float2 pi = pos[s];
         const int cy = (int)skeys[s] - g.col * c.ny;
         const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
@@ -239,6 +275,26 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
         prs[s] = pr;
         ncount[s] = cnt;
     }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* __restrict__ pos,
+                                                           const uint32_t* __restrict__ skeys,
+                                                           const int* __restrict__ cell_start,
+                                                           float* __restrict__ rho, float* __restrict__ prs,
+                                                           int* __restrict__ ncount, uint32_t* __restrict__ nmask,
+                                                           int n_max, TileQueue q, int col_lo, int col_hi,
+                                                           int tile_cells, int cap) {
+    extern __shared__ __align__(16) float4 s_dyn[];
+    float2* s_pos = reinterpret_cast<float2*>(s_dyn);
+    int* s_off = reinterpret_cast<int*>(s_pos + cap);
+    int* s_gs = s_off + PAIR_MAXC + 1;
+    int* s_wave = s_gs + PAIR_MAXC;
+    for_each_tile(q, [&](int col, int trow, int tix) {
+        if (col < col_lo || col >= col_hi) return;  // (the list may cover the force pass's wider range)
+        density_tile<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, col, trow, tile_cells, cap, s_pos,
+                              s_off, s_gs, s_wave, tix);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -411,8 +467,8 @@ __device__ __forceinline__ void integrate_one(const DevConsts& c, float2& p, flo
 template <int THREADS, bool FAST>
 __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s_rec,
                                             uint8_t* s_q, int qn, int lo, int self_off, float2 pi, float2 vi,
-                                            float pres_i, float& fx, float& fy) {
-    const int tid = threadIdx.x;
+                                            float pres_i, float& fx, float& fy, int tix) {
+    const int tid = tix;
 #pragma unroll
     for (int u = 0; u < FORCE_HEAVY_UNROLL - 1; u++) s_q[(qn + u) * THREADS + tid] = (uint8_t)self_off;
     for (int t = 0; __any(t < qn); t += FORCE_HEAVY_UNROLL) {
@@ -466,8 +522,8 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
 template <int THREADS, bool FAST>
 __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* s_rec,
                                              uint8_t* s_q, int j, int hi, int self, float2 pi, float2 vi,
-                                             float pres_i, float& fx, float& fy) {
-    const int tid = threadIdx.x;
+                                             float pres_i, float& fx, float& fy, int tix) {
+    const int tid = tix;
     // the queue holds byte offsets from the start of the lane's range (ranges are <= FORCE_MAX_RANGE long)
     const int lo = j;
     const int self_off = self - lo;
@@ -491,7 +547,7 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* 
                 j += FORCE_SCAN_UNROLL;
             }
         }
-        force_heavy<THREADS, FAST>(c, s_rec, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy);
+        force_heavy<THREADS, FAST>(c, s_rec, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy, tix);
     }
 }
 
@@ -511,9 +567,9 @@ struct PairGroup {
 template <int THREADS>
 __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec* s_rec, uint32_t* s_mask,
                                               const uint32_t* __restrict__ mask_col, int n_max, int lo, int nw,
-                                              int self, float2 pi, float2 vi, float pres_i, float& fx, float& fy) {
+                                              int self, float2 pi, float2 vi, float pres_i, float& fx, float& fy, int tix) {
     constexpr int U = FORCE_HEAVY_UNROLL;
-    const int tid = threadIdx.x;
+    const int tid = tix;
     // The lane's mask words go to LDS first (s_mask[w * THREADS + tid]; one batch of coalesced global
     // loads): the refills inside the pop loop are divergent, and a global load there would stall the
     // wave for a full memory round trip at almost every pop.
@@ -587,46 +643,32 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
 #define FORCE_WAVES_MAX 4
 #endif
 template <bool FUSE, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORCE_WAVES_MAX))) void k_force(DevConsts c, const float2* __restrict__ pos,
-                                                         const float2* __restrict__ vel,
-                                                         const float* __restrict__ rho,
-                                                         const float* __restrict__ prs,
-                                                         const uint32_t* __restrict__ idv,
-                                                         const uint32_t* __restrict__ skeys,
-                                                         const int* __restrict__ cell_start,
-                                                         float2* __restrict__ pos_o, float2* __restrict__ vel_o,
-                                                         int col0, int ncols, int tiles_per_col, int tile_cells,
-                                                         int cap, int own_lo_col, int own_hi_col, float mx, float my,
-                                                         float strength, int allow_fast,
-                                                         const uint32_t* __restrict__ nmask, int n_max) {
-    extern __shared__ __align__(16) float4 s_dyn[];
-    PairRec* s_rec = reinterpret_cast<PairRec*>(s_dyn);
-    int* s_off = reinterpret_cast<int*>(s_rec + cap);
-    int* s_gs = s_off + PAIR_MAXC + 1;
-    int* s_wave = s_gs + PAIR_MAXC;
-    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_wave + 4);
-
-    int tcol, trow;
-    if (!sph_tile_of_block(blockIdx.x, ncols, tiles_per_col, tcol, trow)) return;
-    {   // ghost column of a slab: pass the particles through (cheap test before any setup)
-        int col = col0 + tcol;
-        if (col < own_lo_col || col >= own_hi_col) {
-            int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
-            int lo = cell_start[col * c.ny + cy0], hi = cell_start[col * c.ny + cy1];
-            for (int s = lo + (int)threadIdx.x; s < hi; s += THREADS) {
-                vel_o[s] = vel[s];
-                if (FUSE) pos_o[s] = pos[s];
-            }
-            return;
+__device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __restrict__ pos,
+                                           const float2* __restrict__ vel, const float* __restrict__ rho,
+                                           const float* __restrict__ prs, const uint32_t* __restrict__ idv,
+                                           const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
+                                           float2* __restrict__ pos_o, float2* __restrict__ vel_o, int col, int trow,
+                                           int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my,
+                                           float strength, int allow_fast, const uint32_t* __restrict__ nmask,
+                                           int n_max, PairRec* s_rec, int* s_off, int* s_gs, int* s_wave,
+                                           uint8_t* s_q, int tix) {
+    // ghost column of a slab: pass the particles through (cheap test before any setup)
+    if (col < own_lo_col || col >= own_hi_col) {
+        int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
+        int lo = cell_start[col * c.ny + cy0], hi = cell_start[col * c.ny + cy1];
+        for (int s = lo + tix; s < hi; s += THREADS) {
+            vel_o[s] = vel[s];
+            if (FUSE) pos_o[s] = pos[s];
         }
+        return;
     }
     TileGeom g;
-    if (!tile_setup<THREADS>(c, cell_start, col0 + tcol, trow, tile_cells, g, s_off, s_gs, s_wave)) return;
+    if (!tile_setup<THREADS>(c, cell_start, col, trow, tile_cells, g, s_off, s_gs, s_wave, tix)) return;
     __syncthreads();
     // LDS path: the candidates fit and every stencil range is short enough for the byte queue
     int too_long = 0;
-    if ((int)threadIdx.x < g.cy1 - g.cy0) {
-        const int cy = g.cy0 + (int)threadIdx.x;
+    if (tix < g.cy1 - g.cy0) {
+        const int cy = g.cy0 + tix;
         const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
         too_long = (s_off[3 * r1 + 3] - PAIR_ROW_PAD - s_off[3 * r0]) > FORCE_MAX_RANGE;
     }
@@ -636,9 +678,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
     if (use_lds) {
         int unsafe = allow_fast ? 0 : 1;
         int no_mask = nmask ? 0 : 1;  // k_density's masks: only if no candidate is invalid or non-finite
-        for (int cc = threadIdx.x >> 4; cc < g.ncells; cc += THREADS / 16) {
+        for (int cc = tix >> 4; cc < g.ncells; cc += THREADS / 16) {
             int o = s_off[cc], n = cand_count(s_off, cc), gs = s_gs[cc];
-            for (int k = threadIdx.x & 15; k < n; k += 16) {
+            for (int k = tix & 15; k < n; k += 16) {
                 int j = gs + k;
                 float2 q = pos[j];
                 float2 w = vel[j];
@@ -657,7 +699,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
                 s_rec[o + k] = rec;
             }
         }
-        for (int t = threadIdx.x; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS) {
+        for (int t = tix; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS) {
             int idx = s_off[3 * (t / PAIR_ROW_PAD) + 3] - PAIR_ROW_PAD + (t % PAIR_ROW_PAD);
             PairRec rec;
             rec.aux = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
@@ -674,7 +716,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
     // particle, or with an invalid one, simply have an empty candidate range.
     const int n_iter = (g.own_hi - g.own_lo + THREADS - 1) / THREADS;
     for (int it = 0; it < n_iter; it++) {
-        const int s = g.own_lo + it * THREADS + (int)threadIdx.x;
+        const int s = g.own_lo + it * THREADS + tix;
         const bool have = s < g.own_hi;
         float2 pi = make_float2(0.0f, 0.0f), vi = pi;
         float dens_i = 1.0f, pres_i = 0.0f;
@@ -701,11 +743,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
             }
             if (by_mask)
                 force_by_mask<THREADS>(c, s_rec, reinterpret_cast<uint32_t*>(s_q), nmask + (have ? s : 0), n_max, j, (hi - j + 31) >> 5, self, pi,
-                                       vi, pres_i, fx, fy);
+                                       vi, pres_i, fx, fy, tix);
             else if (fast)
-                force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy);
+                force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
             else
-                force_rounds<THREADS, false>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy);
+                force_rounds<THREADS, false>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
         } else if (have && valid) {
             for (int cc = 3 * r0; cc < 3 * r1 + 3; cc++) {
                 int gs = s_gs[cc], n = cand_count(s_off, cc);
@@ -735,6 +777,27 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, FORC
     }
 }
 
+template <bool FUSE, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_WAVES_MAX, FORCE_WAVES_MAX))) void k_force(
+    DevConsts c, const float2* __restrict__ pos, const float2* __restrict__ vel, const float* __restrict__ rho,
+    const float* __restrict__ prs, const uint32_t* __restrict__ idv, const uint32_t* __restrict__ skeys,
+    const int* __restrict__ cell_start, float2* __restrict__ pos_o, float2* __restrict__ vel_o, TileQueue q, int col_lo,
+    int col_hi, int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my, float strength,
+    int allow_fast, const uint32_t* __restrict__ nmask, int n_max) {
+    extern __shared__ __align__(16) float4 s_dyn[];
+    PairRec* s_rec = reinterpret_cast<PairRec*>(s_dyn);
+    int* s_off = reinterpret_cast<int*>(s_rec + cap);
+    int* s_gs = s_off + PAIR_MAXC + 1;
+    int* s_wave = s_gs + PAIR_MAXC;
+    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_wave + 8);
+    for_each_tile(q, [&](int col, int trow, int tix) {
+        if (col < col_lo || col >= col_hi) return;
+        force_tile<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, col, trow, tile_cells, cap,
+                                  own_lo_col, own_hi_col, mx, my, strength, allow_fast, nmask, n_max, s_rec, s_off, s_gs,
+                                  s_wave, s_q, tix);
+    });
+}
+
 // Stand-alone integrate (serial_integrate, sph.cpp:101-130).  R pos 8 + vel 8 + idv 4, W 16.
 __global__ __launch_bounds__(256) void k_integrate(DevConsts c, float2* __restrict__ pos, float2* __restrict__ vel,
                                                     const uint32_t* __restrict__ idv,
@@ -755,8 +818,68 @@ __global__ __launch_bounds__(256) void k_integrate(DevConsts c, float2* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-static TileMap tile_launch_dims(const SphCtx* c, int col_lo, int col_hi) {
-    return sph_tile_map(col_hi - col_lo, (c->dc.ny + c->tile_cells - 1) / c->tile_cells);
+// Compacts the non-empty tiles of columns [col0, col0 + ncols) into list[] (see for_each_tile).
+// Thread i looks at one tile, in band-major order; a wave appends its hits with one atomic.
+__global__ __launch_bounds__(256) void k_tile_list(const int* __restrict__ cell_start, int ny, int tile_cells,
+                                                    int tiles_per_col, int col0, int ncols, int* __restrict__ list,
+                                                    int* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_band = PAIR_BAND_COLS * tiles_per_col;
+    const int band = i / per_band, r = i % per_band;
+    const int trow = r / PAIR_BAND_COLS, col = col0 + band * PAIR_BAND_COLS + r % PAIR_BAND_COLS;
+    bool hit = false;
+    if (col < col0 + ncols) {
+        const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, ny);
+        hit = cell_start[col * ny + cy1] > cell_start[col * ny + cy0];
+    }
+    const unsigned long long hits = __ballot(hit);
+    const int lane = sph_lane_id();
+    int base = 0;
+    if (lane == 0 && hits) base = atomicAdd(count, __popcll(hits));
+    base = __shfl(base, 0, 64);
+    if (hit) list[base + __popcll(hits & ((1ull << lane) - 1ull))] = col * tiles_per_col + trow;
+}
+
+// (Re)builds the tile list for the current grid, tiling and column range if it is not current.
+static int ensure_tile_list(SphCtx* c, TileQueue& q) {
+    const int lo = c->col_lo - SPHHIP_HALO_COLS > 0 ? c->col_lo - SPHHIP_HALO_COLS : 0;
+    const int hi = c->col_hi + SPHHIP_HALO_COLS < c->dc.nx ? c->col_hi + SPHHIP_HALO_COLS : c->dc.nx;
+    const int tpc = (c->dc.ny + c->tile_cells - 1) / c->tile_cells;
+    int* count = c->counters + 56;
+    if (!(c->tiles_valid && c->tiles_cells == c->tile_cells && c->tiles_lo == lo && c->tiles_hi == hi)) {
+        const int nbands = (hi - lo + PAIR_BAND_COLS - 1) / PAIR_BAND_COLS;
+        const int nthreads = nbands * PAIR_BAND_COLS * tpc;
+        HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_tile_list, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, c->cell_start, c->dc.ny,
+                           c->tile_cells, tpc, lo, hi - lo, c->tile_list, count);
+        LAUNCH_CHECK();
+        c->tiles_valid = true;
+        c->tiles_cells = c->tile_cells;
+        c->tiles_lo = lo;
+        c->tiles_hi = hi;
+    }
+    q.list = c->tile_list;
+    q.count = count;
+    q.host_count = c->d_host_tiles;
+    q.tiles_per_col = tpc;
+    return SPHHIP_OK;
+}
+
+// Grid of a pair kernel: one workgroup per listed tile going by the last count that reached the host
+// (plus slack; the kernels stride, so an underestimate only costs balance), else one resident wave of
+// workgroups.  Always a multiple of 8 (one chunk per XCD).
+static int pair_grid(SphCtx* c, const void* kern, int threads, size_t lds, int& grid) {
+    const int est = *(volatile int*)c->h_host_tiles;
+    if (est >= 0) {
+        grid = (est + est / 128 + 8 + 7) & ~7;
+        return SPHHIP_OK;
+    }
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
+    if (per_cu < 1) per_cu = 1;
+    grid = (c->num_cus * per_cu) & ~7;
+    if (grid < 8) grid = 8;
+    return SPHHIP_OK;
 }
 
 int sph_density_launch(SphCtx* c) {
@@ -765,12 +888,16 @@ int sph_density_launch(SphCtx* c) {
     // one column wider than the owned range: ghost densities are recomputed locally
     int lo = c->col_lo > 0 ? c->col_lo - 1 : 0;
     int hi = c->col_hi < c->dc.nx ? c->col_hi + 1 : c->dc.nx;
-    TileMap tm = tile_launch_dims(c, lo, hi);
+    TileQueue q;
+    int rc = ensure_tile_list(c, q);
+    if (rc) return rc;
     const int th = c->pair_threads;
     size_t lds = pair_lds_bytes(c->pair_cap, false, th);
     auto kern = th == 128 ? k_density<128> : k_density<256>;
-    hipLaunchKernelGGL(kern, dim3(tm.nblocks), dim3(th), lds, c->stream, c->dc, c->pos, c->keys, c->cell_start, c->rho,
-                       c->prs, c->ncount, c->nmask, c->n_max, lo, tm.ncols, tm.tiles_per_col, c->tile_cells, c->pair_cap);
+    int grid = 0;
+    if ((rc = pair_grid(c, reinterpret_cast<const void*>(kern), th, lds, grid))) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, c->pos, c->keys, c->cell_start, c->rho,
+                       c->prs, c->ncount, c->nmask, c->n_max, q, lo, hi, c->tile_cells, c->pair_cap);
     LAUNCH_CHECK();
     c->counts_valid = true;
     c->mask_tile_cells = c->tile_cells;
@@ -782,11 +909,12 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     if (sph_n_grid(c) == 0) return SPHHIP_OK;
     PhaseScope ps(c, SPHHIP_PH_FORCE);
     // owned columns plus the halo on each side (ghost tiles pass their particles through); on a slab
-    // every particle lies inside that range (sphhip_pack_halo keeps nothing farther out), and launching
-    // tiles for the whole global grid would cost one empty workgroup per tile of the other ranks' slabs
+    // every particle lies inside that range (sphhip_pack_halo keeps nothing farther out)
     const int flo = c->col_lo - SPHHIP_HALO_COLS > 0 ? c->col_lo - SPHHIP_HALO_COLS : 0;
     const int fhi = c->col_hi + SPHHIP_HALO_COLS < c->dc.nx ? c->col_hi + SPHHIP_HALO_COLS : c->dc.nx;
-    TileMap tm = tile_launch_dims(c, flo, fhi);
+    TileQueue q;
+    int rc = ensure_tile_list(c, q);
+    if (rc) return rc;
     const int th = c->pair_threads;
     size_t lds = pair_lds_bytes(c->pair_cap, true, th);
     // the masks of the last density pass describe this grid and this tiling
@@ -794,10 +922,12 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
                           c->mask_cap == c->pair_cap;
     auto kern = fuse_integrate ? (th == 128 ? k_force<true, 128> : k_force<true, 256>)
                                : (th == 128 ? k_force<false, 128> : k_force<false, 256>);
-    hipLaunchKernelGGL(kern, dim3(tm.nblocks), dim3(th), lds, c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv,
-                       c->keys, c->cell_start, c->pos2, c->vel2, flo, tm.ncols, tm.tiles_per_col, c->tile_cells,
-                       c->pair_cap, c->col_lo, c->col_hi, mx, my, strength, c->fast_div ? 1 : 0,
-                       masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max);
+    int grid = 0;
+    if ((rc = pair_grid(c, reinterpret_cast<const void*>(kern), th, lds, grid))) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv,
+                       c->keys, c->cell_start, c->pos2, c->vel2, q, flo, fhi, c->tile_cells, c->pair_cap, c->col_lo,
+                       c->col_hi, mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr,
+                       c->n_max);
     LAUNCH_CHECK();
     std::swap(c->vel, c->vel2);
     if (fuse_integrate) {

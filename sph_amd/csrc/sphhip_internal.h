@@ -85,6 +85,12 @@ struct SphCtx {
     int* digit_total = nullptr;                  // SORT_RADIX (+ SORT_RADIX bases)
     int* scan_tmp = nullptr;                     // block partials of the suffix-min scan
     int* counters = nullptr;                     // small device scratch (compaction counters ...)
+    int* tile_list = nullptr;                    // non-empty tiles of the pair kernels (pairs.hip), <= ncell entries
+    bool tiles_valid = false;                    // ... current for this grid, tiles_cells, [tiles_lo, tiles_hi)
+    int tiles_cells = 0, tiles_lo = 0, tiles_hi = 0;
+    int num_cus = 256;
+    int* h_host_tiles = nullptr;                 // mapped host int: tile count of a recent launch (-1: none yet)
+    int* d_host_tiles = nullptr;                 // its device address
     void* staging = nullptr;                     // AoS staging for upload / download (28 B * n_max)
 
     bool profiling = false;
@@ -150,36 +156,5 @@ __device__ __forceinline__ int sph_cell_coord(float x, float x0, float inv_cell,
     return c;
 }
 
-// XCD-aware workgroup -> tile map for the pair kernels.  Workgroups b and b+8 share an XCD (and its
-// L2) under round-robin dispatch.  Grid columns are cut into bands of PAIR_BAND_COLS adjacent
-// columns; band j belongs to XCD j % 8, and an XCD walks its bands row by row, so the workgroups an
-// XCD runs together are horizontally adjacent tiles -- they share two of their three candidate
-// columns through that XCD's L2.  Bands (not one contiguous chunk per XCD) keep all eight XCDs busy
-// when the fluid occupies only part of the domain (dam break).  Speed only, never correctness:
-// the map is a bijection onto a superset of the tiles; out-of-range workgroups exit.
+// Tiles of the pair kernels are listed in bands of PAIR_BAND_COLS adjacent grid columns (pairs.hip).
 constexpr int PAIR_BAND_COLS = 4;
-
-struct TileMap {
-    int ncols, tiles_per_col, nblocks;
-};
-
-static inline TileMap sph_tile_map(int ncols, int tiles_per_col) {
-    TileMap m;
-    m.ncols = ncols;
-    m.tiles_per_col = tiles_per_col;
-    int nbands = (ncols + PAIR_BAND_COLS - 1) / PAIR_BAND_COLS;
-    int bands_per_xcd = (nbands + 7) / 8;
-    m.nblocks = 8 * bands_per_xcd * PAIR_BAND_COLS * tiles_per_col;
-    return m;
-}
-
-// -> false if this workgroup has no tile
-__device__ __forceinline__ bool sph_tile_of_block(int b, int ncols, int tiles_per_col, int& col, int& trow) {
-    int xcd = b & 7, q = b >> 3;
-    int per_band = PAIR_BAND_COLS * tiles_per_col;
-    int band = xcd + 8 * (q / per_band);
-    int r = q % per_band;
-    col = band * PAIR_BAND_COLS + (r % PAIR_BAND_COLS);
-    trow = r / PAIR_BAND_COLS;
-    return col < ncols;
-}
