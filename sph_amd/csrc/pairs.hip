@@ -48,6 +48,7 @@ constexpr int FORCE_QCAP = FORCE_Q + FORCE_SCAN_UNROLL + FORCE_HEAVY_UNROLL;  //
 // +inf: a lane may read up to PAIR_ROW_PAD records past the end of its range without a bounds test
 // (r2 = +inf fails the distance test); the sentinels inside its range fail the same way.
 constexpr int PAIR_ROW_PAD = 3;
+constexpr int PAIR_STAGE_BATCH = 3;  // staging passes whose global loads are issued together (3 x 16 cells >= a 12-cell tile's 42)
 constexpr int FORCE_MAX_RANGE = 256;  // longest 3x3 stencil range (LDS records) the byte queue can index
 constexpr int PAIR_MASK_WORDS = FORCE_MAX_RANGE / 32;  // in-range bit masks handed from k_density to k_force
 static_assert(FORCE_SCAN_UNROLL - 1 <= PAIR_ROW_PAD, "scan unroll reads past the range end");
@@ -111,9 +112,10 @@ __device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __rest
     g.cy1 = min(g.cy0 + tile_cells, c.ny);
     g.ylo = max(g.cy0 - 1, 0);
     g.yhi = min(g.cy1 + 1, c.ny);
+    // (all cell_start loads of the tile are issued together: one memory round trip; tiles come from the
+    // list of non-empty tiles, so there is no early exit to wait for)
     g.own_lo = cell_start[col * c.ny + g.cy0];
     g.own_hi = cell_start[col * c.ny + g.cy1];
-    if (g.own_lo == g.own_hi) return false;
     g.ncells = 3 * (g.yhi - g.ylo);
     int t = tix;
     int cnt = 0, g0 = 0;
@@ -133,7 +135,7 @@ __device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __rest
         s_gs[t] = g0;
     }
     if (t == 0) s_off[g.ncells] = g.total;
-    return true;
+    return g.own_lo != g.own_hi;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -220,13 +222,36 @@ __device__ __forceinline__ void density_tile(const DevConsts& c, const float2* _
                                              int* s_gs, int* s_wave, int tix) {
     TileGeom g;
     if (!tile_setup<THREADS>(c, cell_start, col, trow, tile_cells, g, s_off, s_gs, s_wave, tix)) return;
+    // the first batch of own particles is fetched now, so that the loads overlap the staging below
+    float2 pi0 = make_float2(0.0f, 0.0f);
+    uint32_t key0 = 0;
+    if (g.own_lo + tix < g.own_hi) {
+        pi0 = pos[g.own_lo + tix];
+        key0 = skeys[g.own_lo + tix];
+    }
     __syncthreads();
     const bool use_lds = g.total <= cap;
     if (use_lds) {
-        // 16 lanes per candidate cell, 16 cells per pass
-        for (int cc = tix >> 4; cc < g.ncells; cc += THREADS / 16) {
-            int o = s_off[cc], n = cand_count(s_off, cc), gs = s_gs[cc];
-            for (int k = tix & 15; k < n; k += 16) s_pos[o + k] = pos[gs + k];
+        // 16 lanes per candidate cell, 16 cells per pass, PAIR_STAGE_BATCH passes' loads in flight together
+        for (int cc0 = tix >> 4; cc0 < g.ncells; cc0 += PAIR_STAGE_BATCH * (THREADS / 16)) {
+            float2 v[PAIR_STAGE_BATCH];
+            int dst[PAIR_STAGE_BATCH], src[PAIR_STAGE_BATCH], left[PAIR_STAGE_BATCH];
+#pragma unroll
+            for (int b = 0; b < PAIR_STAGE_BATCH; b++) {
+                const int cc = cc0 + b * (THREADS / 16);
+                left[b] = 0;
+                if (cc < g.ncells) {
+                    dst[b] = s_off[cc] + (tix & 15);
+                    src[b] = s_gs[cc] + (tix & 15);
+                    left[b] = cand_count(s_off, cc) - (tix & 15);
+                    if (left[b] > 0) v[b] = pos[src[b]];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < PAIR_STAGE_BATCH; b++) {
+                if (left[b] > 0) s_pos[dst[b]] = v[b];
+                for (int k = 16; k < left[b]; k += 16) s_pos[dst[b] + k] = pos[src[b] + k];  // cells with > 16 particles
+            }
         }
         for (int t = tix; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS)
             s_pos[s_off[3 * (t / PAIR_ROW_PAD) + 3] - PAIR_ROW_PAD + (t % PAIR_ROW_PAD)] =
@@ -234,8 +259,10 @@ __device__ __forceinline__ void density_tile(const DevConsts& c, const float2* _
         __syncthreads();
     }
     for (int s = g.own_lo + tix; s < g.own_hi; s += THREADS) {
-        const float2 pi = pos[s];
-        const int cy = (int)skeys[s] - g.col * c.ny;
+        const bool first = s == g.own_lo + tix;
+        const float2 pi = first ? pi0 : pos[s];
+        const uint32_t key = first ? key0 : skeys[s];
+        const int cy = (int)key - g.col * c.ny;
         const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
         float dens = 0.0f;
         int cnt = 0;
@@ -642,6 +669,31 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
 #ifndef FORCE_WAVES_MAX
 #define FORCE_WAVES_MAX 4
 #endif
+// One own particle of a force tile (registers).
+struct OwnParticle {
+    float2 p, v;
+    float d, pr;
+    uint32_t idv, key;
+    __device__ __forceinline__ void load(int s, bool have, const float2* __restrict__ pos,
+                                         const float2* __restrict__ vel, const float* __restrict__ rho,
+                                         const float* __restrict__ prs, const uint32_t* __restrict__ idvs,
+                                         const uint32_t* __restrict__ skeys) {
+        p = v = make_float2(0.0f, 0.0f);
+        d = 1.0f;
+        pr = 0.0f;
+        idv = SPH_INVALID_BIT;
+        key = 0;
+        if (have) {
+            p = pos[s];
+            v = vel[s];
+            d = rho[s];
+            pr = prs[s];
+            idv = idvs[s];
+            key = skeys[s];
+        }
+    }
+};
+
 template <bool FUSE, int THREADS>
 __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __restrict__ pos,
                                            const float2* __restrict__ vel, const float* __restrict__ rho,
@@ -664,6 +716,9 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
     }
     TileGeom g;
     if (!tile_setup<THREADS>(c, cell_start, col, trow, tile_cells, g, s_off, s_gs, s_wave, tix)) return;
+    // the first batch of own particles is fetched now, so that the loads overlap the staging below
+    OwnParticle own0;
+    own0.load(g.own_lo + tix, g.own_lo + tix < g.own_hi, pos, vel, rho, prs, idv, skeys);
     __syncthreads();
     // LDS path: the candidates fit and every stencil range is short enough for the byte queue
     int too_long = 0;
@@ -678,25 +733,50 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
     if (use_lds) {
         int unsafe = allow_fast ? 0 : 1;
         int no_mask = nmask ? 0 : 1;  // k_density's masks: only if no candidate is invalid or non-finite
-        for (int cc = tix >> 4; cc < g.ncells; cc += THREADS / 16) {
-            int o = s_off[cc], n = cand_count(s_off, cc), gs = s_gs[cc];
-            for (int k = tix & 15; k < n; k += 16) {
-                int j = gs + k;
-                float2 q = pos[j];
-                float2 w = vel[j];
-                float dj = rho[j], pj = prs[j];
-                // exact_div.h is used only if every density / pressure of the tile is in its safe range
-                unsafe |= (dj == 0.0f || !sph_safe_operand(dj) || !sph_safe_operand(pj)) ? 1 : 0;
-                // `!particles[j].valid` (sph.cpp:63): an invalid j is staged at +inf so that
-                // r2 = +inf >= H*H skips it with the same compare that skips far particles.
-                no_mask |= (!(fabsf(q.x) < inf) || !(fabsf(q.y) < inf) || (idv[j] & SPH_INVALID_BIT)) ? 1 : 0;
-                if (idv[j] & SPH_INVALID_BIT) q = make_float2(inf, inf);
-                PairRec rec;
-                rec.aux = make_float4(w.x, w.y, dj, pj);
-                rec.pos = q;
-                rec.yd = sph_rcp_refined(dj);
-                rec.pad = 0.0f;
-                s_rec[o + k] = rec;
+        auto stage = [&](int dst, float2 q, float2 w, float dj, float pj, uint32_t idj) {
+            // exact_div.h is used only if every density / pressure of the tile is in its safe range
+            unsafe |= (dj == 0.0f || !sph_safe_operand(dj) || !sph_safe_operand(pj)) ? 1 : 0;
+            // `!particles[j].valid` (sph.cpp:63): an invalid j is staged at +inf so that
+            // r2 = +inf >= H*H skips it with the same compare that skips far particles.
+            no_mask |= (!(fabsf(q.x) < inf) || !(fabsf(q.y) < inf) || (idj & SPH_INVALID_BIT)) ? 1 : 0;
+            if (idj & SPH_INVALID_BIT) q = make_float2(inf, inf);
+            PairRec rec;
+            rec.aux = make_float4(w.x, w.y, dj, pj);
+            rec.pos = q;
+            rec.yd = sph_rcp_refined(dj);
+            rec.pad = 0.0f;
+            s_rec[dst] = rec;
+        };
+        // 16 lanes per candidate cell, 16 cells per pass, PAIR_STAGE_BATCH passes' loads in flight together
+        for (int cc0 = tix >> 4; cc0 < g.ncells; cc0 += PAIR_STAGE_BATCH * (THREADS / 16)) {
+            float2 q[PAIR_STAGE_BATCH], w[PAIR_STAGE_BATCH];
+            float dj[PAIR_STAGE_BATCH], pj[PAIR_STAGE_BATCH];
+            uint32_t idj[PAIR_STAGE_BATCH];
+            int dst[PAIR_STAGE_BATCH], src[PAIR_STAGE_BATCH], left[PAIR_STAGE_BATCH];
+#pragma unroll
+            for (int b = 0; b < PAIR_STAGE_BATCH; b++) {
+                const int cc = cc0 + b * (THREADS / 16);
+                left[b] = 0;
+                if (cc < g.ncells) {
+                    dst[b] = s_off[cc] + (tix & 15);
+                    src[b] = s_gs[cc] + (tix & 15);
+                    left[b] = cand_count(s_off, cc) - (tix & 15);
+                    if (left[b] > 0) {
+                        q[b] = pos[src[b]];
+                        w[b] = vel[src[b]];
+                        dj[b] = rho[src[b]];
+                        pj[b] = prs[src[b]];
+                        idj[b] = idv[src[b]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < PAIR_STAGE_BATCH; b++) {
+                if (left[b] > 0) stage(dst[b], q[b], w[b], dj[b], pj[b], idj[b]);
+                for (int k = 16; k < left[b]; k += 16) {  // cells with > 16 particles
+                    const int j = src[b] + k;
+                    stage(dst[b] + k, pos[j], vel[j], rho[j], prs[j], idv[j]);
+                }
             }
         }
         for (int t = tix; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS) {
@@ -718,17 +798,14 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
     for (int it = 0; it < n_iter; it++) {
         const int s = g.own_lo + it * THREADS + tix;
         const bool have = s < g.own_hi;
-        float2 pi = make_float2(0.0f, 0.0f), vi = pi;
-        float dens_i = 1.0f, pres_i = 0.0f;
-        bool valid = false;
+        OwnParticle own = own0;
+        if (it > 0) own.load(s, have, pos, vel, rho, prs, idv, skeys);  // tiles with more than THREADS particles
+        float2 pi = own.p, vi = own.v;
+        const float dens_i = own.d, pres_i = own.pr;
+        const bool valid = have && !(own.idv & SPH_INVALID_BIT);
         int r0 = 0, r1 = -1, self_cell = 0;
         if (have) {
-            pi = pos[s];
-            vi = vel[s];
-            valid = !(idv[s] & SPH_INVALID_BIT);
-            dens_i = rho[s];
-            pres_i = prs[s];
-            const int cy = (int)skeys[s] - g.col * c.ny;
+            const int cy = (int)own.key - g.col * c.ny;
             r0 = max(cy - 1, 0) - g.ylo;
             r1 = min(cy + 1, c.ny - 1) - g.ylo;
             self_cell = 3 * (cy - g.ylo) + 1;
@@ -742,8 +819,8 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
                 self = s_off[self_cell] + (s - s_gs[self_cell]);
             }
             if (by_mask)
-                force_by_mask<THREADS>(c, s_rec, reinterpret_cast<uint32_t*>(s_q), nmask + (have ? s : 0), n_max, j, (hi - j + 31) >> 5, self, pi,
-                                       vi, pres_i, fx, fy, tix);
+                force_by_mask<THREADS>(c, s_rec, reinterpret_cast<uint32_t*>(s_q), nmask + (have ? s : 0), n_max, j,
+                                       (hi - j + 31) >> 5, self, pi, vi, pres_i, fx, fy, tix);
             else if (fast)
                 force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
             else
