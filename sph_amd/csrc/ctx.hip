@@ -148,7 +148,7 @@ static hipError_t dmalloc(T** p, size_t count) {
 
 static void free_all(SphCtx* c) {
     void* ptrs[] = {c->pos, c->vel, c->pos2, c->vel2, c->rho, c->prs, c->rho2, c->prs2, c->idv, c->idv2,
-                    c->ncount, c->nmask, c->keys, c->keys2, c->perm, c->perm2, c->ids_sorted, c->cell_start, c->block_hist,
+                    c->ncount, c->nmask, c->keys, c->keys2, c->perm, c->perm2, c->ids_sorted, c->cell_buf[0], c->cell_buf[1], c->block_hist,
                     c->digit_total, c->scan_tmp, c->counters, c->tile_list, c->staging};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -214,7 +214,16 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     ok(dmalloc(&c->nmask, n * 8));
     ok(dmalloc(&c->keys, n)); ok(dmalloc(&c->keys2, n)); ok(dmalloc(&c->perm, n)); ok(dmalloc(&c->perm2, n));
     ok(dmalloc(&c->ids_sorted, n));
-    ok(dmalloc(&c->cell_start, (size_t)c->ncell + 1));
+    {   // two cell tables, each followed by the partial sums of its scan (see grid.hip)
+        const size_t words = (size_t)c->ncell + 1 + ((size_t)c->ncell + 1 + 2047) / 2048 + 8;
+        for (int b = 0; b < 2; b++) {
+            ok(dmalloc(&c->cell_buf[b], words));
+            if (e == hipSuccess) ok(hipMemset(c->cell_buf[b], 0, sizeof(int) * words));
+        }
+        c->cell_start = c->cell_buf[0];
+        c->cell_cur = 0;
+        c->cell_next_zeroed = true;
+    }
     ok(dmalloc(&c->block_hist, (size_t)SORT_RADIX * nblocks));
     ok(dmalloc(&c->digit_total, 2 * SORT_RADIX));
     ok(dmalloc(&c->scan_tmp, (size_t)(c->ncell + 1 + 2047) / 2048 + 1));

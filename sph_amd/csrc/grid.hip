@@ -9,6 +9,8 @@
 // All of it is HBM-bound integer work: coalesced 4/8-byte streams, LDS for the per-tile ranking.
 #include "sphhip_internal.h"
 
+constexpr int SCAN_CHUNK = 2048;  // cells per workgroup of the scans over the cell table
+
 // ---------------------------------------------------------------------------------------------
 // cell hash: key per slot + identity permutation.   R pos 8 B, W key 4 B + idx 4 B per particle
 // ---------------------------------------------------------------------------------------------
@@ -193,7 +195,6 @@ __global__ __launch_bounds__(256) void k_cell_marks(const uint32_t* __restrict__
 // Suffix-min scan over the ncell+1 marks -> monotone cell_start (empty cells inherit the start of
 // the next non-empty cell).  Three small kernels: chunk minima, suffix-min of the chunk minima
 // (one workgroup), apply.  Chunk = 2048 cells.
-constexpr int SCAN_CHUNK = 2048;
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -309,7 +310,18 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
                                                        const float* __restrict__ rho, const float* __restrict__ prs,
                                                        const uint32_t* __restrict__ idv, float2* __restrict__ pos_o,
                                                        float2* __restrict__ vel_o, float* __restrict__ rho_o,
-                                                       float* __restrict__ prs_o, uint32_t* __restrict__ idv_o) {
+                                                       float* __restrict__ prs_o, uint32_t* __restrict__ idv_o,
+                                                       int reorder_blocks, TileListArgs tl, int ny,
+                                                       int* __restrict__ zero_buf, int zero_words) {
+    if ((int)blockIdx.x >= reorder_blocks) {
+        // tail workgroups: list the non-empty tiles of the pair kernels for this grid, and zero the idle
+        // cell table for the next build -- two small launches saved per step
+        const int i = ((int)blockIdx.x - reorder_blocks) * (int)blockDim.x + (int)threadIdx.x;
+        sph_tile_list_thread(i, cell_start, ny, tl.tile_cells, tl.tiles_per_col, tl.col0, tl.ncols, tl.list, tl.count);
+        const int stride = ((int)gridDim.x - reorder_blocks) * (int)blockDim.x;
+        for (int k = i; k < zero_words; k += stride) zero_buf[k] = 0;
+        return;
+    }
     const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
@@ -409,7 +421,9 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const int* __restrict__ a, 
     if (threadIdx.x == 0) part[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
 }
 
-__global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ a, int len, const int* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ a, int len, const int* __restrict__ part,
+                                                     int* __restrict__ zero_me) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;  // the tile counter of the pair kernels
     __shared__ int buf[SCAN_CHUNK];
     __shared__ int wsum[4];
     __shared__ int wtot[4];
@@ -466,12 +480,18 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     const int n = sph_n_grid(c);  // exact count, or the capacity while the count is only known on the device
     hipStream_t st = c->stream;
     const int ncell = c->ncell;
+    const int len = ncell + 1;
+    const int nparts = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    const int table_words = len + nparts;  // cell table + the partial sums of its scan
     if (c->grid_counting) {
-        const int len = ncell + 1;
-        const int nparts = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
         {
             PhaseScope ps(c, SPHHIP_PH_HASH);
-            HIP_TRY(hipMemsetAsync(c->cell_start, 0, sizeof(int) * (size_t)len, st));
+            // switch to the idle cell table; it was zeroed by the previous build's reorder kernel
+            const int next = 1 - c->cell_cur;
+            if (!c->cell_next_zeroed) HIP_TRY(hipMemsetAsync(c->cell_buf[next], 0, sizeof(int) * (size_t)table_words, st));
+            c->cell_cur = next;
+            c->cell_start = c->cell_buf[next];
+            c->cell_next_zeroed = false;
             if (n > 0) {
                 hipLaunchKernelGGL(k_cell_count, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, c->d_n, c->keys2,
                                    c->perm2, c->cell_start);
@@ -480,8 +500,11 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
         }
         {
             PhaseScope ps(c, SPHHIP_PH_CELLS);
-            hipLaunchKernelGGL(k_scan_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp);
-            hipLaunchKernelGGL(k_scan_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp);
+            // (the chunk sums are a kernel of their own: accumulating them with atomics in k_cell_count puts
+            // thousands of atomics on a few hundred addresses, 0.4 us each -- measured 0.1 ms)
+            hipLaunchKernelGGL(k_scan_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->cell_start + len);
+            hipLaunchKernelGGL(k_scan_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->cell_start + len,
+                               c->counters + SPH_TILE_COUNT_SLOT);
             LAUNCH_CHECK();
         }
         if (n > 0) {
@@ -524,30 +547,46 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
         }
         {
             PhaseScope ps(c, SPHHIP_PH_CELLS);
-            const int len = ncell + 1;
+            c->cell_next_zeroed = false;  // (this path leaves both tables dirty)
             HIP_TRY(hipMemsetAsync(c->cell_start, 0x7f, sizeof(int) * (size_t)len, st));
             if (n > 0) {
                 hipLaunchKernelGGL(k_cell_marks, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm, c->idv, c->d_n,
                                    c->cell_start, c->ids_sorted);
             }
-            int nparts = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
             hipLaunchKernelGGL(k_sufmin_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp);
             hipLaunchKernelGGL(k_sufmin_parts, dim3(1), dim3(256), 0, st, c->scan_tmp, nparts);
             hipLaunchKernelGGL(k_sufmin_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp, c->d_n);
             LAUNCH_CHECK();
         }
     }
+    c->tiles_valid = false;
     if (n > 0) {
         PhaseScope ps(c, SPHHIP_PH_REORDER);
+        const int nb = (n + 255) / 256;
+        // tail workgroups (counting path only): tile list of the pair kernels + zeroing of the idle cell table
+        TileListArgs tl = {};
+        int tail = 0, lo = 0, hi = 0;
+        if (c->grid_counting) {
+            sph_tile_list_args(c, tl, lo, hi);
+            tail = (tl.nthreads + 255) / 256;
+        }
+        int* zero_buf = c->cell_buf[1 - c->cell_cur];
         if (carry_density)
-            hipLaunchKernelGGL(k_rank_reorder<true>, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm,
-                               c->ids_sorted, c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
-                               c->vel2, c->rho2, c->prs2, c->idv2);
+            hipLaunchKernelGGL(k_rank_reorder<true>, dim3(nb + tail), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
+                               c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
+                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf, table_words);
         else
-            hipLaunchKernelGGL(k_rank_reorder<false>, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm,
-                               c->ids_sorted, c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
-                               c->vel2, c->rho2, c->prs2, c->idv2);
+            hipLaunchKernelGGL(k_rank_reorder<false>, dim3(nb + tail), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
+                               c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
+                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf, table_words);
         LAUNCH_CHECK();
+        if (tail > 0) {
+            c->cell_next_zeroed = true;
+            c->tiles_valid = true;
+            c->tiles_cells = c->tile_cells;
+            c->tiles_lo = lo;
+            c->tiles_hi = hi;
+        }
         std::swap(c->pos, c->pos2);
         std::swap(c->vel, c->vel2);
         if (carry_density) {
@@ -558,7 +597,6 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     }
     c->grid_valid = true;
     c->counts_valid = false;
-    c->tiles_valid = false;
     // when only part of the columns is owned, remember which slot range that is (ghost dropping)
     c->slice_valid = (c->col_lo > 0 || c->col_hi < c->dc.nx);
     c->slice_lo = c->col_lo;

@@ -895,40 +895,24 @@ __global__ __launch_bounds__(256) void k_integrate(DevConsts c, float2* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Compacts the non-empty tiles of columns [col0, col0 + ncols) into list[] (see for_each_tile).
-// Thread i looks at one tile, in band-major order; a wave appends its hits with one atomic.
+// Compacts the non-empty tiles of columns [col0, col0 + ncols) into list[] (see for_each_tile); the grid
+// build normally does this in the tail of its reorder kernel (grid.hip), this kernel is the fallback.
 __global__ __launch_bounds__(256) void k_tile_list(const int* __restrict__ cell_start, int ny, int tile_cells,
                                                     int tiles_per_col, int col0, int ncols, int* __restrict__ list,
                                                     int* __restrict__ count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int per_band = PAIR_BAND_COLS * tiles_per_col;
-    const int band = i / per_band, r = i % per_band;
-    const int trow = r / PAIR_BAND_COLS, col = col0 + band * PAIR_BAND_COLS + r % PAIR_BAND_COLS;
-    bool hit = false;
-    if (col < col0 + ncols) {
-        const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, ny);
-        hit = cell_start[col * ny + cy1] > cell_start[col * ny + cy0];
-    }
-    const unsigned long long hits = __ballot(hit);
-    const int lane = sph_lane_id();
-    int base = 0;
-    if (lane == 0 && hits) base = atomicAdd(count, __popcll(hits));
-    base = __shfl(base, 0, 64);
-    if (hit) list[base + __popcll(hits & ((1ull << lane) - 1ull))] = col * tiles_per_col + trow;
+    sph_tile_list_thread(blockIdx.x * blockDim.x + threadIdx.x, cell_start, ny, tile_cells, tiles_per_col, col0, ncols,
+                         list, count);
 }
 
 // (Re)builds the tile list for the current grid, tiling and column range if it is not current.
 static int ensure_tile_list(SphCtx* c, TileQueue& q) {
-    const int lo = c->col_lo - SPHHIP_HALO_COLS > 0 ? c->col_lo - SPHHIP_HALO_COLS : 0;
-    const int hi = c->col_hi + SPHHIP_HALO_COLS < c->dc.nx ? c->col_hi + SPHHIP_HALO_COLS : c->dc.nx;
-    const int tpc = (c->dc.ny + c->tile_cells - 1) / c->tile_cells;
-    int* count = c->counters + 56;
+    TileListArgs tl;
+    int lo, hi;
+    sph_tile_list_args(c, tl, lo, hi);
     if (!(c->tiles_valid && c->tiles_cells == c->tile_cells && c->tiles_lo == lo && c->tiles_hi == hi)) {
-        const int nbands = (hi - lo + PAIR_BAND_COLS - 1) / PAIR_BAND_COLS;
-        const int nthreads = nbands * PAIR_BAND_COLS * tpc;
-        HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_tile_list, dim3((nthreads + 255) / 256), dim3(256), 0, c->stream, c->cell_start, c->dc.ny,
-                           c->tile_cells, tpc, lo, hi - lo, c->tile_list, count);
+        HIP_TRY(hipMemsetAsync(tl.count, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_tile_list, dim3((tl.nthreads + 255) / 256), dim3(256), 0, c->stream, c->cell_start, c->dc.ny,
+                           tl.tile_cells, tl.tiles_per_col, tl.col0, tl.ncols, tl.list, tl.count);
         LAUNCH_CHECK();
         c->tiles_valid = true;
         c->tiles_cells = c->tile_cells;
@@ -936,9 +920,9 @@ static int ensure_tile_list(SphCtx* c, TileQueue& q) {
         c->tiles_hi = hi;
     }
     q.list = c->tile_list;
-    q.count = count;
+    q.count = tl.count;
     q.host_count = c->d_host_tiles;
-    q.tiles_per_col = tpc;
+    q.tiles_per_col = tl.tiles_per_col;
     return SPHHIP_OK;
 }
 

@@ -80,7 +80,10 @@ struct SphCtx {
     uint32_t *keys = nullptr, *keys2 = nullptr;  // cell key per slot (ping-pong during the sort)
     uint32_t *perm = nullptr, *perm2 = nullptr;  // source slot per sorted slot
     uint32_t* ids_sorted = nullptr;              // id per sorted slot before the in-cell id ranking
-    int* cell_start = nullptr;                   // ncell + 1, monotone
+    int* cell_start = nullptr;                   // ncell + 1, monotone (= cell_buf[cell_cur])
+    int* cell_buf[2] = {nullptr, nullptr};       // two cell tables (+ scan partials): the idle one is zeroed ahead
+    int cell_cur = 0;
+    bool cell_next_zeroed = false;               // cell_buf[1 - cell_cur] is all zero
     int* block_hist = nullptr;                   // SORT_RADIX * nblocks
     int* digit_total = nullptr;                  // SORT_RADIX (+ SORT_RADIX bases)
     int* scan_tmp = nullptr;                     // block partials of the suffix-min scan
@@ -158,3 +161,48 @@ __device__ __forceinline__ int sph_cell_coord(float x, float x0, float inv_cell,
 
 // Tiles of the pair kernels are listed in bands of PAIR_BAND_COLS adjacent grid columns (pairs.hip).
 constexpr int PAIR_BAND_COLS = 4;
+
+// ---- tile list of the pair kernels (pairs.hip: for_each_tile) --------------------------------
+// Thread i of a compaction pass looks at one tile of columns [col0, col0 + ncols), in band-major order,
+// and appends it to list[] if it holds particles; a wave appends its hits with one atomic.
+__device__ __forceinline__ void sph_tile_list_thread(int i, const int* __restrict__ cell_start, int ny,
+                                                     int tile_cells, int tiles_per_col, int col0, int ncols,
+                                                     int* __restrict__ list, int* __restrict__ count) {
+    const int per_band = PAIR_BAND_COLS * tiles_per_col;
+    const int band = i / per_band, r = i % per_band;
+    const int trow = r / PAIR_BAND_COLS, col = col0 + band * PAIR_BAND_COLS + r % PAIR_BAND_COLS;
+    bool hit = false;
+    if (col < col0 + ncols) {
+        const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, ny);
+        hit = cell_start[col * ny + cy1] > cell_start[col * ny + cy0];
+    }
+    const unsigned long long hits = __ballot(hit);
+    const int lane = sph_lane_id();
+    int base = 0;
+    if (lane == 0 && hits) base = atomicAdd(count, __popcll(hits));
+    base = __shfl(base, 0, 64);
+    if (hit) list[base + __popcll(hits & ((1ull << lane) - 1ull))] = col * tiles_per_col + trow;
+}
+
+struct TileListArgs {
+    int tile_cells, tiles_per_col, col0, ncols, nthreads;
+    int* list;
+    int* count;
+};
+
+constexpr int SPH_TILE_COUNT_SLOT = 56;  // SphCtx::counters[56]: number of listed tiles
+
+// Tile list parameters for the current tiling and column range: owned columns plus the halo (the force
+// pass's range; the density pass skips what it does not need).
+static inline void sph_tile_list_args(const SphCtx* c, TileListArgs& tl, int& lo, int& hi) {
+    lo = c->col_lo - SPHHIP_HALO_COLS > 0 ? c->col_lo - SPHHIP_HALO_COLS : 0;
+    hi = c->col_hi + SPHHIP_HALO_COLS < c->dc.nx ? c->col_hi + SPHHIP_HALO_COLS : c->dc.nx;
+    tl.tile_cells = c->tile_cells;
+    tl.tiles_per_col = (c->dc.ny + c->tile_cells - 1) / c->tile_cells;
+    tl.col0 = lo;
+    tl.ncols = hi - lo;
+    const int nbands = (hi - lo + PAIR_BAND_COLS - 1) / PAIR_BAND_COLS;
+    tl.nthreads = nbands * PAIR_BAND_COLS * tl.tiles_per_col;
+    tl.list = c->tile_list;
+    tl.count = c->counters + SPH_TILE_COUNT_SLOT;
+}
