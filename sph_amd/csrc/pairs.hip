@@ -597,19 +597,22 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
                                               int self, float2 pi, float2 vi, float pres_i, float& fx, float& fy, int tix) {
     constexpr int U = FORCE_HEAVY_UNROLL;
     const int tid = tix;
-    // The lane's mask words go to LDS first (s_mask[w * THREADS + tid]; one batch of coalesced global
-    // loads): the refills inside the pop loop are divergent, and a global load there would stall the
-    // wave for a full memory round trip at almost every pop.
+    // The lane's mask words are in LDS, s_mask[w * THREADS + tid] (force_tile puts the first batch's there
+    // before staging; later batches are fetched here): the refills inside the pop loop are divergent, and a
+    // global load there would stall the wave for a full memory round trip at almost every pop.
+    if (mask_col) {
 #pragma unroll
-    for (int k = 0; k < PAIR_MASK_WORDS; k++)
-        if (k < nw) s_mask[k * THREADS + tid] = mask_col[(size_t)k * n_max];
+        for (int k = 0; k < PAIR_MASK_WORDS; k++)
+            if (k < nw) s_mask[k * THREADS + tid] = mask_col[(size_t)k * n_max];
+    }
     int w = 0;
     int base = lo;  // LDS index of the candidate in bit 31 of the current word
     uint32_t m = 0, m_next = 0;
     if (nw > 0) m = s_mask[tid];
     if (nw > 1) m_next = s_mask[THREADS + tid];
 #if defined(FORCE_EXPERIMENT) && FORCE_EXPERIMENT == 2
-    nw = 0; m = 0;
+    nw = 0;
+    m = 0;  // ablation: no pair loop
 #endif
     // pops the next U set bits of the lane and starts the LDS reads of those records
     auto fetch = [&](PairGroup& g) {
@@ -719,6 +722,16 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
     // the first batch of own particles is fetched now, so that the loads overlap the staging below
     OwnParticle own0;
     own0.load(g.own_lo + tix, g.own_lo + tix < g.own_hi, pos, vel, rho, prs, idv, skeys);
+    // ... and their mask words (all PAIR_MASK_WORDS of them: how many are meaningful is only known after
+    // the scan) go straight to their LDS slots, s_mask[w * THREADS + tix]
+    uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_q);
+    if (nmask && g.own_lo + tix < g.own_hi) {
+        uint32_t mw[PAIR_MASK_WORDS];
+#pragma unroll
+        for (int k = 0; k < PAIR_MASK_WORDS; k++) mw[k] = nmask[(size_t)k * n_max + g.own_lo + tix];
+#pragma unroll
+        for (int k = 0; k < PAIR_MASK_WORDS; k++) s_mask[k * THREADS + tix] = mw[k];
+    }
     __syncthreads();
     // LDS path: the candidates fit and every stencil range is short enough for the byte queue
     int too_long = 0;
@@ -819,7 +832,7 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
                 self = s_off[self_cell] + (s - s_gs[self_cell]);
             }
             if (by_mask)
-                force_by_mask<THREADS>(c, s_rec, reinterpret_cast<uint32_t*>(s_q), nmask + (have ? s : 0), n_max, j,
+                force_by_mask<THREADS>(c, s_rec, s_mask, it > 0 ? nmask + (have ? s : 0) : (const uint32_t*)nullptr, n_max, j,
                                        (hi - j + 31) >> 5, self, pi, vi, pres_i, fx, fy, tix);
             else if (fast)
                 force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
