@@ -60,7 +60,7 @@ json.dump(summary, open(os.path.join("profiles", tag + "_pmc_summary.json"), "w"
 tf = os.path.join("profiles", "traffic.json")
 traffic = json.load(open(tf)) if os.path.exists(tf) else {}
 for k, d in summary.items():
-    if k.startswith("k_force<true>") and "hbm_bytes" in d:
+    if k.startswith("k_force<true") and "hbm_bytes" in d:
         traffic.setdefault(workload, {})["k_force_bytes_per_launch"] = d["hbm_bytes"]
         traffic[workload]["source"] = "profiles/%s_pmc_summary.json" % tag
 json.dump(traffic, open(tf, "w"), indent=1, sort_keys=True)
