@@ -59,7 +59,7 @@ def cpu_baseline(n_gpus):
     cols = 256 if cores < 12 else 362
     params, a = scenes.dam_break(cols)
     O.omp_step_allpairs(params, a, 0)
-    steps = 2
+    steps = 8  # ~10 s of CPU work on 16 cores
     t0 = time.perf_counter()
     O.omp_step_allpairs(params, a, steps)
     dt = time.perf_counter() - t0
