@@ -193,6 +193,7 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
         if (const char* e = getenv("SPHHIP_FAST_DIV")) c->fast_div = c->fast_div && atoi(e) != 0;
     }
     if (const char* e = getenv("SPHHIP_USE_MASKS")) c->use_masks = atoi(e) != 0;
+    if (const char* e = getenv("SPHHIP_LAZY_PACK")) c->lazy_pack = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_GRID")) c->grid_counting = std::string(e) != "radix";
     if (const char* e = getenv("SPHHIP_PAIR_THREADS")) {
         int v = atoi(e);
@@ -358,6 +359,8 @@ extern "C" int sphhip_upload(SphCtx* c, const void* aos28, int n, int id_base) {
     c->grid_valid = false;
     c->counts_valid = false;
     c->slice_valid = false;
+    c->pending_drop = false;
+    c->tail_appended = false;
     return SPHHIP_OK;
 }
 
@@ -556,11 +559,8 @@ static_assert(sizeof(HaloRec) == 20, "halo record");
 // only while c->n_exact; sph_sync_n reads it back (one stream synchronisation) when a caller needs it.
 enum { SPH_ERR_HALO_OVERFLOW = 1, SPH_ERR_MSG_BAD = 2, SPH_ERR_CAPACITY = 4 };
 
-static int* n_slot_next(SphCtx* c) { return c->n_ring + ((c->n_slot + 1) & 7); }
-static void n_advance(SphCtx* c) {
-    c->n_slot = (c->n_slot + 1) & 7;
-    c->d_n = c->n_ring + c->n_slot;
-}
+static int* n_slot_next(SphCtx* c) { return sph_n_slot_next(c); }
+static void n_advance(SphCtx* c) { sph_n_advance(c); }
 
 int sph_set_n_host(SphCtx* c, int n) {
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->d_n, n, 1, c->stream));
@@ -628,7 +628,8 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split(DevConsts c, const int*
                                                 uint32_t* __restrict__ idv_o, int* __restrict__ cnt_left,
                                                 int* __restrict__ cnt_right, int* __restrict__ cnt_keep,
                                                 int* __restrict__ err, const int* __restrict__ cell_start,
-                                                int slice_lo_cell, int slice_hi_cell) {
+                                                const int* __restrict__ n_sorted, int slice_lo_cell,
+                                                int slice_hi_cell) {
     __shared__ int s_cnt[SPLIT_THREADS / 64];
     __shared__ int s_base;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -636,7 +637,9 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split(DevConsts c, const int*
     // After a step on a slab the state still holds the ghost copies (unmoved).  Slots are still in
     // the order of that step's sort, so the particles this rank integrated are exactly the slot
     // range of its owned columns; everything else is a stale ghost and is dropped here.
-    if (live && cell_start && (i < cell_start[slice_lo_cell] || i >= cell_start[slice_hi_cell])) live = false;
+    // (Slots from *n_sorted on were appended after that sort: received records, always kept.)
+    if (live && cell_start && i < *n_sorted && (i < cell_start[slice_lo_cell] || i >= cell_start[slice_hi_cell]))
+        live = false;
     float2 p = make_float2(0.0f, 0.0f), v = p;
     uint32_t w = 0;
     int col = 0;
@@ -690,8 +693,8 @@ static int split_enqueue(SphCtx* c, int send_hi_left, int send_lo_right, int kee
         hipLaunchKernelGGL(k_split, dim3((ng + SPLIT_THREADS - 1) / SPLIT_THREADS), dim3(SPLIT_THREADS), 0, c->stream, c->dc, c->d_n, c->pos, c->vel,
                            c->rho, c->prs, c->idv, send_hi_left, send_lo_right, keep_lo, keep_hi, d_left, cap_left,
                            d_right, cap_right, c->pos2, c->vel2, c->rho2, c->prs2, c->idv2, cnt_left, cnt_right, keep,
-                           c->d_err, c->slice_valid ? c->cell_start : nullptr, c->slice_lo * c->dc.ny,
-                           c->slice_hi * c->dc.ny);
+                           c->d_err, c->slice_valid ? c->cell_start : nullptr, c->counters + SPH_N_SORTED_SLOT,
+                           c->slice_lo * c->dc.ny, c->slice_hi * c->dc.ny);
         LAUNCH_CHECK();
     }
     n_advance(c);
@@ -704,7 +707,75 @@ static int split_enqueue(SphCtx* c, int send_hi_left, int send_lo_right, int kee
     c->grid_valid = false;
     c->counts_valid = false;
     c->slice_valid = false;
+    c->pending_drop = false;
     return SPHHIP_OK;
+}
+
+// The same classification for the exchange only, WITHOUT compacting the state: after a step the slots are
+// still in the order of the step's sort, and a particle moves less than a cell per step, so everything
+// that must go left sits in the slot range of the first SPHHIP_HALO_COLS + 1 owned columns (likewise
+// right).  Only those ranges are read; the stale ghost copies stay where they are and are dropped by the
+// next grid build (SphCtx::pending_drop, k_cell_count).  Workgroups [0, nb) serve the left message,
+// [nb, 2 nb) the right one; record slots are claimed with one atomic per workgroup pass on a counter in
+// the context, and the last workgroup to finish (ticket) writes both counts into the message headers and
+// re-arms the counters: no memset, no host round trip.
+constexpr int PACK_BLOCKS = 16;
+
+__global__ __launch_bounds__(256) void k_pack_boundary(DevConsts c, const float2* __restrict__ pos,
+                                                        const float2* __restrict__ vel,
+                                                        const uint32_t* __restrict__ idv,
+                                                        const int* __restrict__ cell_start, int left_lo_cell,
+                                                        int left_hi_cell, int right_lo_cell, int right_hi_cell,
+                                                        int send_hi_left, int send_lo_right, HaloRec* __restrict__ left,
+                                                        HaloRec* __restrict__ right, int cap, int* __restrict__ msg_cnt,
+                                                        int* __restrict__ ticket, int* __restrict__ err) {
+    __shared__ int s_cnt[4];
+    __shared__ int s_base;
+    const int side = blockIdx.x / PACK_BLOCKS, b = blockIdx.x % PACK_BLOCKS;
+    HaloRec* out = side ? right : left;
+    if (out) {
+        const int lo = cell_start[side ? right_lo_cell : left_lo_cell], hi = cell_start[side ? right_hi_cell : left_hi_cell];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int i0 = lo + b * 256; i0 < hi; i0 += PACK_BLOCKS * 256) {  // uniform trip count over the workgroup
+            const int i = i0 + (int)threadIdx.x;
+            bool send = false;
+            HaloRec r = {0.0f, 0.0f, 0.0f, 0.0f, 0u};
+            if (i < hi) {
+                const float2 p = pos[i], v = vel[i];
+                const int col = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
+                send = side ? col >= send_lo_right : col < send_hi_left;
+                r = {p.x, p.y, v.x, v.y, idv[i]};
+            }
+            const unsigned long long bal = __ballot(send);
+            if (lane == 0) s_cnt[wave] = __popcll(bal);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+                s_base = tot ? atomicAdd(&msg_cnt[side], tot) : 0;
+            }
+            __syncthreads();
+            int k = s_base + __popcll(bal & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; w++) k += s_cnt[w];
+            if (send) {
+                if (k < cap) out[1 + k] = r;  // record 0 is the header
+                else atomicOr(err, SPH_ERR_HALO_OVERFLOW);
+            }
+            __syncthreads();
+        }
+    }
+    // last workgroup out: counts into the headers, counters back to zero
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = atomicAdd(ticket, 1);
+        if (done == (int)gridDim.x - 1) {
+            __threadfence();
+            const int nl = atomicExch(&msg_cnt[0], 0), nr = atomicExch(&msg_cnt[1], 0);
+            if (left) left[0] = {__int_as_float(nl < cap ? nl : cap), 0.0f, 0.0f, 0.0f, 0u};
+            if (right) right[0] = {__int_as_float(nr < cap ? nr : cap), 0.0f, 0.0f, 0.0f, 0u};
+            atomicExch(ticket, 0);
+        }
+    }
 }
 
 static int split_impl(SphCtx* c, int send_hi_left, int send_lo_right, int keep_lo, int keep_hi, void* d_left,
@@ -730,6 +801,23 @@ extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_r
     HaloRec* l = (HaloRec*)d_msg_left;
     HaloRec* r = (HaloRec*)d_msg_right;
     // record 0 of a message is its header (word 0 = record count); records follow from row 1
+    if (c->slice_valid && !c->pending_drop && !c->tail_appended && c->grid_counting && c->lazy_pack && c->slice_lo == c->col_lo &&
+        c->slice_hi == c->col_hi && (!l || send_hi_left <= c->col_lo + SPHHIP_HALO_COLS) &&
+        (!r || send_lo_right >= c->col_hi - SPHHIP_HALO_COLS)) {
+        // fast path: the state is in the slot order of the last sort (a step has run since, nothing else)
+        const int ny = c->dc.ny;
+        const int reach = SPHHIP_HALO_COLS + 1;  // a particle crosses less than one column per step
+        const int l_hi = c->col_lo + reach < c->col_hi ? c->col_lo + reach : c->col_hi;
+        const int r_lo = c->col_hi - reach > c->col_lo ? c->col_hi - reach : c->col_lo;
+        hipLaunchKernelGGL(k_pack_boundary, dim3(2 * PACK_BLOCKS), dim3(256), 0, c->stream, c->dc, c->pos, c->vel, c->idv,
+                           c->cell_start, c->col_lo * ny, l_hi * ny, r_lo * ny, c->col_hi * ny, send_hi_left, send_lo_right,
+                           l, r, cap, c->counters + SPH_MSG_COUNT_SLOT, c->counters + SPH_MSG_TICKET_SLOT, c->d_err);
+        LAUNCH_CHECK();
+        c->pending_drop = true;
+        c->grid_valid = false;  // positions have moved since the sort (the fused step leaves it false anyway)
+        c->counts_valid = false;
+        return SPHHIP_OK;
+    }
     return split_enqueue(c, l ? send_hi_left : -1, r ? send_lo_right : 0x7fffffff, c->col_lo - SPHHIP_HALO_COLS,
                          c->col_hi + SPHHIP_HALO_COLS, l ? l + 1 : nullptr, l ? cap : 0, l ? (int*)l : c->counters,
                          r ? r + 1 : nullptr, r ? cap : 0, r ? (int*)r : c->counters + 1);
@@ -792,10 +880,8 @@ __global__ __launch_bounds__(256) void k_append(const HaloRec* __restrict__ rec,
 }
 
 static int append_enqueue(SphCtx* c, const HaloRec* rec, const int* d_cnt, int cnt_imm, int cap) {
-    if (c->slice_valid && c->have_state) {  // stale ghosts of the last step must not mix with new records
-        int rc = sphhip_drop_ghosts(c);
-        if (rc) return rc;
-    }
+    // (stale ghost copies of the last step may still be in the arrays: they are told from the appended
+    // records by their slot, below / from the count at the last sort -- see k_split, k_cell_count)
     int* out = n_slot_next(c);
     int grid = (cap + 255) / 256;
     if (grid < 1) grid = 1;
@@ -806,6 +892,7 @@ static int append_enqueue(SphCtx* c, const HaloRec* rec, const int* d_cnt, int c
     c->have_state = true;
     c->grid_valid = false;
     c->counts_valid = false;
+    c->tail_appended = true;
     return SPHHIP_OK;
 }
 

@@ -355,12 +355,20 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cell_count(DevConsts c, const float2* __restrict__ pos,
                                                      const int* __restrict__ d_n, uint32_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ rank, int* __restrict__ cell_cnt) {
+                                                     uint32_t* __restrict__ rank, int* __restrict__ cell_cnt,
+                                                     const int* __restrict__ prev_table,
+                                                     const int* __restrict__ n_sorted, int drop_lo_cell,
+                                                     int drop_hi_cell) {
     const int n = *d_n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i < n;
+    // Lazy ghost drop (slab steps): the first *n_sorted slots are still in the order of the previous sort,
+    // whose table says which slot range the owned columns were; everything else among them is a stale
+    // ghost copy.  Such a particle gets the key 0xffffffff, is not counted and not scattered.
+    bool dead = false;
+    if (prev_table && ok && i < *n_sorted) dead = i < prev_table[drop_lo_cell] || i >= prev_table[drop_hi_cell];
     uint32_t key = 0xffffffffu;
-    if (ok) {
+    if (ok && !dead) {
         float2 p = pos[i];
         int cx = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
         int cy = sph_cell_coord(p.y, c.ymin, c.inv_cell, c.ny);
@@ -368,14 +376,14 @@ __global__ __launch_bounds__(256) void k_cell_count(DevConsts c, const float2* _
     }
     const int lane = sph_lane_id();
     const uint32_t prev = __shfl_up(key, 1, 64);
-    const bool head = ok && (lane == 0 || prev != key);
+    const bool head = ok && (lane == 0 || prev != key);  // (runs of dead particles are runs too, but count nothing)
     const unsigned long long heads = __ballot(head);
     const int n_ok = __popcll(__ballot(ok));  // the in-range lanes are a prefix of the wave
     const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);  // lanes 0..lane
     const unsigned long long below = heads & upto;
     const int start = below ? 63 - __clzll((long long)below) : 0;  // head lane of this lane's run
     int base = 0;
-    if (head) {
+    if (head && !dead) {
         const unsigned long long above = heads & ~upto;
         const int next = above ? __ffsll((long long)above) - 1 : n_ok;
         base = atomicAdd(&cell_cnt[key], next - lane);
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t* __restrict
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = keys[i];
+    if (k == 0xffffffffu) return;  // dropped (k_cell_count)
     const int slot = cell_start[k] + (int)rank[i];
     skeys[slot] = k;
     perm[slot] = (uint32_t)i;
@@ -422,7 +431,8 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const int* __restrict__ a, 
 }
 
 __global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ a, int len, const int* __restrict__ part,
-                                                     int* __restrict__ zero_me) {
+                                                     int* __restrict__ zero_me, int* __restrict__ n_sorted,
+                                                     int* __restrict__ n_out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;  // the tile counter of the pair kernels
     __shared__ int buf[SCAN_CHUNK];
     __shared__ int wsum[4];
@@ -466,6 +476,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ a, int len
     for (int r = 0; r < 8; r++) {
         int i = base + r * 256 + tid;
         if (i < len) a[i] = buf[r * 256 + tid];
+        if (i == len - 1) {  // a[ncell] = number of particles sorted: the count after a lazy ghost drop
+            *n_sorted = buf[r * 256 + tid];
+            if (n_out) *n_out = buf[r * 256 + tid];
+        }
     }
 }
 
@@ -489,12 +503,14 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             // switch to the idle cell table; it was zeroed by the previous build's reorder kernel
             const int next = 1 - c->cell_cur;
             if (!c->cell_next_zeroed) HIP_TRY(hipMemsetAsync(c->cell_buf[next], 0, sizeof(int) * (size_t)table_words, st));
+            const int* prev_table = (c->pending_drop && c->slice_valid) ? c->cell_start : nullptr;
             c->cell_cur = next;
             c->cell_start = c->cell_buf[next];
             c->cell_next_zeroed = false;
             if (n > 0) {
                 hipLaunchKernelGGL(k_cell_count, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, c->d_n, c->keys2,
-                                   c->perm2, c->cell_start);
+                                   c->perm2, c->cell_start, prev_table, c->counters + SPH_N_SORTED_SLOT,
+                                   c->slice_lo * c->dc.ny, c->slice_hi * c->dc.ny);
                 LAUNCH_CHECK();
             }
         }
@@ -504,7 +520,8 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             // thousands of atomics on a few hundred addresses, 0.4 us each -- measured 0.1 ms)
             hipLaunchKernelGGL(k_scan_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->cell_start + len);
             hipLaunchKernelGGL(k_scan_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->cell_start + len,
-                               c->counters + SPH_TILE_COUNT_SLOT);
+                               c->counters + SPH_TILE_COUNT_SLOT, c->counters + SPH_N_SORTED_SLOT,
+                               c->pending_drop ? sph_n_slot_next(c) : (int*)nullptr);
             LAUNCH_CHECK();
         }
         if (n > 0) {
@@ -512,6 +529,11 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             hipLaunchKernelGGL(k_cell_scatter, dim3((n + 255) / 256), dim3(256), 0, st, c->keys2, c->perm2, c->idv, c->d_n,
                                c->cell_start, c->keys, c->perm, c->ids_sorted);
             LAUNCH_CHECK();
+        }
+        if (c->pending_drop) {  // the scan wrote the count without the dropped ghosts into the next ring slot
+            sph_n_advance(c);
+            c->n_exact = false;
+            c->pending_drop = false;
         }
     } else {
         if (n > 0) {
@@ -597,8 +619,9 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     }
     c->grid_valid = true;
     c->counts_valid = false;
-    // when only part of the columns is owned, remember which slot range that is (ghost dropping)
-    c->slice_valid = (c->col_lo > 0 || c->col_hi < c->dc.nx);
+    c->tail_appended = false;
+    // remember which slot range the owned columns are (ghost dropping on slabs)
+    c->slice_valid = true;
     c->slice_lo = c->col_lo;
     c->slice_hi = c->col_hi;
     return SPHHIP_OK;

@@ -59,6 +59,9 @@ struct SphCtx {
     bool grid_valid = false;
     bool counts_valid = false;
     bool slice_valid = false;    // slots of [slice_lo, slice_hi) columns (at the last sort) = owned particles
+    bool tail_appended = false;  // records were appended behind the sorted slots since the last sort
+    bool pending_drop = false;   // the stale ghosts outside that slice are still in the arrays: the next grid
+                                 // build drops them (sphhip_pack_halo_async's fast path does not compact)
     int slice_lo = 0, slice_hi = 0;
     int col_lo = 0, col_hi = 0;  // owned columns (default: all)
     int tile_cells = 12;         // cells of a column per pair-kernel workgroup
@@ -74,6 +77,7 @@ struct SphCtx {
     uint32_t* nmask = nullptr;  // in-range bit masks of the last density pass: word w of slot s at [w * n_max + s]
     int mask_tile_cells = 0, mask_cap = 0;  // tiling the masks were built with
     bool grid_counting = true;  // counting sort by cell (SPHHIP_GRID=radix: the LSD radix sort)
+    bool lazy_pack = true;      // SPHHIP_LAZY_PACK=0: sphhip_pack_halo_async always compacts
     bool use_masks = true;      // SPHHIP_USE_MASKS=0: k_force always scans
 
     // grid
@@ -191,6 +195,16 @@ struct TileListArgs {
 };
 
 constexpr int SPH_TILE_COUNT_SLOT = 56;  // SphCtx::counters[56]: number of listed tiles
+constexpr int SPH_N_SORTED_SLOT = 57;    // counters[57]: particle count after the last grid build
+constexpr int SPH_MSG_COUNT_SLOT = 58;   // counters[58..59]: record counts of the halo messages being packed
+constexpr int SPH_MSG_TICKET_SLOT = 60;  // counters[60]: finished workgroups of the pack kernel
+
+// ring of device-side particle counts (see ctx.hip)
+static inline int* sph_n_slot_next(SphCtx* c) { return c->n_ring + ((c->n_slot + 1) & 7); }
+static inline void sph_n_advance(SphCtx* c) {
+    c->n_slot = (c->n_slot + 1) & 7;
+    c->d_n = c->n_ring + c->n_slot;
+}
 
 // Tile list parameters for the current tiling and column range: owned columns plus the halo (the force
 // pass's range; the density pass skips what it does not need).
