@@ -53,6 +53,24 @@ void hip_cleanupSimulation();
 // the per-step prints of the reference are kept out of the timed region.
 int HIP_main(int N);
 int HIP_main_headless(int N, int steps, const char* dump_path);
+
+// Scripted stand-in for the interactive loop of X_main (SPH/serial_main.cpp:68-105): the mouse state is
+// a list of events instead of GLFW callbacks, the frames go to image files instead of a window.
+// From step `step` on the cursor is at window pixel (px, py) of the reference's 800x800 window with
+// button 0 = none, 1 = left (strength +50000), 2 = right (-50000); mapped to simulation space exactly
+// as serial_main.cpp:72-75.  Events must be in ascending step order.
+struct HipMouseEvent {
+    int step;
+    float px, py;
+    int button;
+};
+// Runs `steps` steps of the default scene under the script.  Every `frame_every` steps (0: never), and
+// after the last step, the state is fetched (off any timed path; stands in for updateVBO,
+// SPH/sph.cu:207-216) and written as a binary PPM "<frame_prefix><step, 6 digits>.ppm": 800x800, one
+// pixel per valid particle with finite position (serial_main.cpp:92-99), coloured by pressure as
+// SPH/openMP_sph.cpp:218-219.  `dump_path` as in HIP_main_headless.  Returns 0, or -1 on error.
+int HIP_main_scripted(int N, int steps, const HipMouseEvent* script, int n_events, int frame_every,
+                      const char* frame_prefix, const char* dump_path);
 float HIP_performance_test(int N);
 // Last error text of the shim ("" if none); the reference's functions have no error channel, so
 // failures are reported here and on stderr, never by exit() (contrast SPH/sph.cuh:17-23).

@@ -190,3 +190,91 @@ int HIP_main_headless(int N, int steps, const char* dump_path) {
 }
 
 int HIP_main(int N) { return HIP_main_headless(N, 1000, nullptr); }
+
+namespace {
+// One frame: 800x800 binary PPM, y up as glOrtho(0, 2, 0, 2) (serial_main.cpp:60), point colour of
+// display() in SPH/openMP_sph.cpp:218-219.
+bool write_frame(const std::string& path, const std::vector<Particle>& v, int n) {
+    const int W = 800, H = 800;
+    std::vector<unsigned char> img((size_t)W * H * 3, 0);
+    const float stiffness = 1000.0f, rest = 1000.0f;  // SPH/sph.h:15-16
+    for (int i = 0; i < n; i++) {
+        const Particle& p = v[i];
+        if (!p.valid || std::isnan(p.pos.x) || std::isnan(p.pos.y)) continue;  // serial_main.cpp:94
+        int x = (int)std::floor(p.pos.x / 2.0f * W), y = (int)std::floor((1.0f - p.pos.y / 2.0f) * H);
+        if (x < 0 || x >= W || y < 0 || y >= H) continue;
+        float t = p.pressure / (stiffness * rest * 0.5f);
+        if (!(t < 1.0f)) t = 1.0f;
+        if (!(t > 0.0f)) t = 0.0f;
+        unsigned char* px = &img[((size_t)y * W + x) * 3];
+        px[0] = (unsigned char)std::lround(255.0f * (0.2f + 0.8f * t));
+        px[1] = (unsigned char)std::lround(255.0f * (0.6f + 0.4f * t));
+        px[2] = 255;
+    }
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fprintf(f, "P6\n%d %d\n255\n", W, H);
+    bool ok = std::fwrite(img.data(), 1, img.size(), f) == img.size();
+    std::fclose(f);
+    return ok;
+}
+}  // namespace
+
+int HIP_main_scripted(int N, int steps, const HipMouseEvent* script, int n_events, int frame_every,
+                      const char* frame_prefix, const char* dump_path) {
+    g_err.clear();
+    if (N <= 0 || steps < 0 || n_events < 0 || (n_events > 0 && !script) || frame_every < 0) {
+        g_err = "HIP_main_scripted: bad argument";
+        return -1;
+    }
+    for (int e = 1; e < n_events; e++)
+        if (script[e].step < script[e - 1].step) {
+            g_err = "HIP_main_scripted: events must be in ascending step order";
+            return -1;
+        }
+    std::vector<Particle> particles;
+    hip_initSimulation(particles, N);
+    if (!upload(particles, N)) return -1;
+    const bool frames = frame_every > 0 && frame_prefix && *frame_prefix;
+    auto frame = [&](int step) {
+        if (!download(particles, N)) return false;
+        char name[32];
+        std::snprintf(name, sizeof name, "%06d.ppm", step);
+        if (!write_frame(std::string(frame_prefix) + name, particles, N)) {
+            g_err = "HIP_main_scripted: cannot write frame";
+            return false;
+        }
+        return true;
+    };
+    int done = 0, ev = 0;
+    float mx = 0.0f, my = 0.0f, strength = 0.0f;
+    while (done < steps) {
+        while (ev < n_events && script[ev].step <= done) {  // serial_main.cpp:72-75
+            mx = (float)((script[ev].px / 800.0) * 2.0);
+            my = (float)(2.0 - (script[ev].py / 800.0) * 2.0);
+            strength = script[ev].button == 1 ? 50000.0f : script[ev].button == 2 ? -50000.0f : 0.0f;
+            ev++;
+        }
+        int until = steps;  // run with this mouse state until the next event, frame or the end
+        if (ev < n_events && script[ev].step < until) until = script[ev].step;
+        if (frames) {
+            int next_frame = (done / frame_every + 1) * frame_every;
+            if (next_frame < until) until = next_frame;
+        }
+        int rc = sphhip_step(g_ctx, mx, my, strength, until - done);
+        if (rc) {
+            fail("sphhip_step", rc);
+            return -1;
+        }
+        done = until;
+        if (frames && (done % frame_every == 0 || done == steps) && !frame(done)) return -1;
+    }
+    if (!download(particles, N)) return -1;
+    if (dump_path && *dump_path) {
+        FILE* f = std::fopen(dump_path, "wb");
+        if (!f) return -1;
+        std::fwrite(particles.data(), sizeof(Particle), (size_t)N, f);
+        std::fclose(f);
+    }
+    return 0;
+}

@@ -81,3 +81,31 @@ def test_headless_dispatcher(tmp_path):
     subprocess.run([CLI, "--n", "1024", "--mode", "run", "--steps", "10", "--dump", dump], check=True, timeout=120)
     got = np.fromfile(dump, PARTICLE_DTYPE)
     assert orc.same_bits(got, O.step_cells(P, O.init_lattice(1024), 10))
+
+
+def test_scripted_mouse_and_frames(tmp_path):
+    """Scripted stand-in for the interactive loop (serial_main.cpp:68-105): mouse events by step, pixel ->
+    simulation mapping of serial_main.cpp:72-75, frames as PPM files.  The final state must equal the
+    oracle stepped with the same per-step mouse input, bit for bit."""
+    script = [(0, 400.0, 400.0, 0), (5, 300.0, 500.0, 1), (12, 520.0, 260.0, 2), (20, 0.0, 0.0, 0)]
+    sp = tmp_path / "mouse.txt"
+    sp.write_text("".join("%d %g %g %d\n" % e for e in script))
+    dump, prefix = str(tmp_path / "state.bin"), str(tmp_path / "frame_")
+    steps = 26
+    subprocess.run([CLI, "--n", "1024", "--mode", "run", "--steps", str(steps), "--mouse-script", str(sp), "--frames", "8",
+                    "--frame-prefix", prefix, "--dump", dump], check=True, timeout=120)
+    a = O.init_lattice(1024)
+    for s in range(steps):
+        _, px, py, button = [e for e in script if e[0] <= s][-1]
+        mx = np.float32((px / 800.0) * 2.0)
+        my = np.float32(2.0 - (py / 800.0) * 2.0)
+        strength = {0: 0.0, 1: 50000.0, 2: -50000.0}[button]
+        a = O.step_cells(P, a, 1, (float(mx), float(my)), strength)
+    got = np.fromfile(dump, PARTICLE_DTYPE)
+    assert orc.same_bits(got, a)
+    for s in (8, 16, 24, 26):  # every 8 steps and after the last one
+        raw = open(prefix + "%06d.ppm" % s, "rb").read()
+        assert raw.startswith(b"P6\n800 800\n255\n") and len(raw) == 15 + 800 * 800 * 3
+        img = np.frombuffer(raw[15:], np.uint8).reshape(800, 800, 3)
+        lit = (img[:, :, 2] == 255).sum()
+        assert 900 <= lit <= 1024  # one pixel per particle (a few may share a pixel)
