@@ -160,6 +160,13 @@ int sphhip_get_cells(SphCtx* ctx, int* keys, int* order, int* cell_start, int* c
  * k-th smallest id.  Written by the most recent density pass. */
 int sphhip_get_neighbor_counts(SphCtx* ctx, int* counts, int n);
 
+/* serial_stepSimulation (SPH/sph.cpp:166-171) in the reference's own evaluation order: all pairs in
+ * ascending j, and serial_computeForces' in-place velocity update (sph.cpp:96-97: particle i sees the
+ * updated velocity of every j < i).  Inherently sequential in i -- a parity tool for n <= 4096
+ * (SPHHIP_ECAPACITY above), O(n^2); particle ids must be 0..n-1.  Results equal the reference's serial
+ * step bit for bit (sphhip_step computes the snapshot semantics of SPH/MPI_sph.cpp instead). */
+int sphhip_step_reference_order(SphCtx* ctx, float mouse_x, float mouse_y, float strength, int nsteps);
+
 /* ---- slab decomposition hooks (replace the index-block + Allgather scheme of
  *      mpi_computeStep, SPH/MPI_sph.cpp:135-166,255-257) --------------------------------- */
 

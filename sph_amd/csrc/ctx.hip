@@ -466,6 +466,12 @@ extern "C" int sphhip_step(SphCtx* c, float mx, float my, float strength, int ns
     return SPHHIP_OK;
 }
 
+extern "C" int sphhip_step_reference_order(SphCtx* c, float mx, float my, float strength, int nsteps) {
+    NEED_EXACT(c);
+    if (nsteps < 0) return fail(SPHHIP_EINVAL, "sphhip_step_reference_order: nsteps < 0");
+    return sph_step_reference_order(c, mx, my, strength, nsteps);
+}
+
 // ---- diagnostics ----------------------------------------------------------------------------
 extern "C" int sphhip_get_cells(SphCtx* c, int* keys, int* order, int* cell_start, int* cell_end) {
     NEED_EXACT(c);

@@ -908,6 +908,157 @@ __global__ __launch_bounds__(256) void k_integrate(DevConsts c, float2* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// Reference-order mode (parity tool): the reference's serial step exactly as written --
+// all pairs in ascending j, and the in-place velocity update of serial_computeForces (sph.cpp:96-97:
+// particle i sees the already-updated velocity of every j < i).  That is sequential in i, so it is
+// for small N only: the state is put in id order (slot == id) and one wavefront walks i = 0..n-1 with
+// the whole state in LDS; for every i the lanes evaluate 64 consecutive j at a time and the in-range
+// terms are added in lane order (v_readlane), i.e. in ascending j like the reference's loop.  Same
+// arithmetic helpers as the production kernels (the generic `/`, sqrtf instantiation).  Results equal
+// the compiled reference bit for bit (tests: golden F2 trajectory, F6 mouse).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_to_id_order(const int* __restrict__ d_n, const float2* __restrict__ pos,
+                                                      const float2* __restrict__ vel, const float* __restrict__ rho,
+                                                      const float* __restrict__ prs, const uint32_t* __restrict__ idv,
+                                                      float2* __restrict__ pos_o, float2* __restrict__ vel_o,
+                                                      float* __restrict__ rho_o, float* __restrict__ prs_o,
+                                                      uint32_t* __restrict__ idv_o, int* __restrict__ bad) {
+    const int n = *d_n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = idv[i];
+    const uint32_t id = w & SPH_ID_MASK;
+    if (id >= (uint32_t)n) {  // ids must be a permutation of 0..n-1
+        atomicOr(bad, 1);
+        return;
+    }
+    pos_o[id] = pos[i];
+    vel_o[id] = vel[i];
+    rho_o[id] = rho[i];
+    prs_o[id] = prs[i];
+    idv_o[id] = w;
+}
+
+// serial_computeDensityPressure (sph.cpp:41-55): every i in parallel, j ascending over ALL particles.
+__global__ __launch_bounds__(256) void k_ref_density(DevConsts c, int n, const float2* __restrict__ pos,
+                                                      float* __restrict__ rho, float* __restrict__ prs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 pi = pos[i];
+    float dens = 0.0f;
+    int cnt = 0;
+    for (int j = 0; j < n; j++) density_acc(c, pi, pos[j], dens, cnt);
+    float pr = c.stiffness * (dens - c.rest_density);
+    if (pr < 0.0f) pr = 0.0f;
+    rho[i] = dens;
+    prs[i] = pr;
+}
+
+constexpr int REF_MAX_N = 4096;  // 24 B of LDS per particle
+
+// serial_computeForces (sph.cpp:57-99) + serial_integrate (sph.cpp:101-130); one wavefront.
+__global__ __launch_bounds__(64) void k_ref_forces_integrate(DevConsts c, int n, float2* __restrict__ pos,
+                                                              float2* __restrict__ vel, const float* __restrict__ rho,
+                                                              const float* __restrict__ prs,
+                                                              const uint32_t* __restrict__ idv, float mx, float my,
+                                                              float strength) {
+    extern __shared__ __align__(16) float4 s_dyn[];
+    float2* s_pos = reinterpret_cast<float2*>(s_dyn);
+    float2* s_vel = s_pos + n;
+    float* s_rho = reinterpret_cast<float*>(s_vel + n);
+    float* s_prs = s_rho + n;
+    uint32_t* s_ok = reinterpret_cast<uint32_t*>(s_prs + n);
+    const int lane = threadIdx.x;
+    for (int k = lane; k < n; k += 64) {
+        s_pos[k] = pos[k];
+        s_vel[k] = vel[k];
+        s_rho[k] = rho[k];
+        s_prs[k] = prs[k];
+        s_ok[k] = (idv[k] & SPH_INVALID_BIT) ? 0u : 1u;
+    }
+    __syncthreads();
+    const int nchunk = (n + 63) / 64;
+    for (int i = 0; i < n; i++) {
+        if (!s_ok[i]) continue;  // sph.cpp:59 (uniform)
+        const float2 pi = s_pos[i];
+        float2 vi = s_vel[i];
+        const float dens_i = s_rho[i], pres_i = s_prs[i];
+        float fx = 0.0f, fy = 0.0f;
+        for (int ch = 0; ch < nchunk; ch++) {
+            const int j = ch * 64 + lane;
+            float tx = 0.0f, ty = 0.0f;
+            bool in = false;
+            if (j < n && j != i && s_ok[j]) {  // sph.cpp:63
+                const float2 q = s_pos[j];
+                const float rx = pi.x - q.x, ry = pi.y - q.y;
+                const float r2 = rx * rx + ry * ry;
+                if (!(r2 >= c.h2)) {  // sph.cpp:66
+                    in = true;
+                    const float2 w = s_vel[j];  // already updated for j < i: the reference's in-place update
+                    force_term(c, rx, ry, r2, pres_i, vi.x, vi.y, make_float4(w.x, w.y, s_rho[j], s_prs[j]), tx, ty);
+                }
+            }
+            unsigned long long bal = __ballot(in);
+            while (bal) {  // ascending j
+                const int b = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                fx += __shfl(tx, b, 64);
+                fy += __shfl(ty, b, 64);
+            }
+        }
+        float2 p = pi;
+        force_epilogue<false>(c, fx, fy, p, vi, dens_i, mx, my, strength);
+        if (lane == 0) s_vel[i] = vi;  // sph.cpp:96-97
+        __syncthreads();                // one wavefront: orders the LDS write before the next i reads it
+    }
+    for (int k = lane; k < n; k += 64) {  // serial_integrate
+        float2 p = s_pos[k], v = s_vel[k];
+        if (s_ok[k]) integrate_one(c, p, v);
+        pos[k] = p;
+        vel[k] = v;
+    }
+}
+
+int sph_step_reference_order(SphCtx* c, float mx, float my, float strength, int nsteps) {
+    const int n = c->n;
+    if (n > REF_MAX_N) {
+        sph_set_error("sphhip_step_reference_order: more than 4096 particles (this mode is a sequential parity tool)");
+        return SPHHIP_ECAPACITY;
+    }
+    if (n == 0 || nsteps == 0) return SPHHIP_OK;
+    int* bad = c->counters + 8;
+    HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_to_id_order, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_n, c->pos, c->vel, c->rho, c->prs,
+                       c->idv, c->pos2, c->vel2, c->rho2, c->prs2, c->idv2, bad);
+    LAUNCH_CHECK();
+    int h_bad = 0;
+    HIP_TRY(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h_bad) {
+        sph_set_error("sphhip_step_reference_order: particle ids are not a permutation of 0..n-1");
+        return SPHHIP_ESTATE;
+    }
+    std::swap(c->pos, c->pos2);
+    std::swap(c->vel, c->vel2);
+    std::swap(c->rho, c->rho2);
+    std::swap(c->prs, c->prs2);
+    std::swap(c->idv, c->idv2);
+    c->grid_valid = false;
+    c->counts_valid = false;
+    c->slice_valid = false;
+    c->pending_drop = false;
+    c->tail_appended = false;
+    const size_t lds = (size_t)n * 28;
+    for (int s = 0; s < nsteps; s++) {
+        hipLaunchKernelGGL(k_ref_density, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dc, n, c->pos, c->rho, c->prs);
+        hipLaunchKernelGGL(k_ref_forces_integrate, dim3(1), dim3(64), lds, c->stream, c->dc, n, c->pos, c->vel, c->rho,
+                           c->prs, c->idv, mx, my, strength);
+        LAUNCH_CHECK();
+    }
+    return SPHHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Compacts the non-empty tiles of columns [col0, col0 + ncols) into list[] (see for_each_tile); the grid
 // build normally does this in the tail of its reorder kernel (grid.hip), this kernel is the fallback.
 __global__ __launch_bounds__(256) void k_tile_list(const int* __restrict__ cell_start, int ny, int tile_cells,

@@ -126,6 +126,7 @@ int sph_grid_build(SphCtx* c, bool carry_density);
 int sph_density_launch(SphCtx* c);
 int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate);
 int sph_integrate_launch(SphCtx* c);
+int sph_step_reference_order(SphCtx* c, float mx, float my, float strength, int nsteps);
 int sph_set_n_host(SphCtx* c, int n);
 int sph_sync_n(SphCtx* c);
 // launch bound for per-particle kernels: the exact count, or the capacity while only the device knows it

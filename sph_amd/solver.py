@@ -82,6 +82,11 @@ class Solver:
     def stepSimulation(self, mousePos=(0.0, 0.0), interactionStrength=0.0, nsteps=1):
         _lib.check(self.L.sphhip_step(self.h, mousePos[0], mousePos[1], interactionStrength, int(nsteps)))
 
+    def stepSimulationReferenceOrder(self, mousePos=(0.0, 0.0), interactionStrength=0.0, nsteps=1):
+        """serial_stepSimulation (SPH/sph.cpp:166-171) with the reference's own all-pairs order and in-place
+        velocity update: sequential parity tool for n <= 4096, bit-exact against the reference's serial path."""
+        _lib.check(self.L.sphhip_step_reference_order(self.h, mousePos[0], mousePos[1], interactionStrength, int(nsteps)))
+
     def synchronize(self):
         _lib.check(self.L.sphhip_synchronize(self.h))
 

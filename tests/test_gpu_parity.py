@@ -189,6 +189,31 @@ def test_trajectory_vs_reference_serial_golden(solver):
     assert orc.same_bits(s100, want)
 
 
+def test_reference_order_mode_equals_reference_serial(solver):
+    """The sequential reference-order mode (all pairs in ascending j, in-place velocity update) against the
+    golden vectors the compiled reference produced: bit-exact, including the mouse force."""
+    g = G("f2_serial_traj_n1024")
+    solver.upload(g["s0"])
+    done = 0
+    for k in (1, 10, 50, 100, 200):
+        solver.stepSimulationReferenceOrder(nsteps=k - done)
+        done = k
+        assert orc.same_bits(solver.download(), g["s%d" % k]), k
+    a = G("f9_invalid")["state"]
+    solver.upload(a)
+    solver.stepSimulationReferenceOrder(nsteps=1)
+    assert orc.same_bits(solver.download(), G("f9_invalid")["after_1step"])
+    for mouse, strength in (((0.8, 0.9), 50000.0), ((1.2, 0.4), -50000.0)):
+        b = g["s50"]
+        solver.upload(b)
+        solver.stepSimulationReferenceOrder(mouse, strength, 3)
+        assert orc.same_bits(solver.download(), O.step_allpairs(P, b.copy(), 3, mouse, strength, flags=orc.GAUSS_SEIDEL))
+    with pytest.raises(Exception):
+        big = scenes.lattice(5000)
+        solver.upload(big)
+        solver.stepSimulationReferenceOrder(nsteps=1)
+
+
 def test_invalid_particles_golden(solver):
     g = G("f9_invalid")
     solver.upload(g["state"])
