@@ -302,6 +302,28 @@ def test_scaled_scene_miniatures():
         assert np.abs(got["pos"] - ref["pos"]).max() <= 1e-6
 
 
+def test_full_size_dam_break_bit_exact():
+    """BASELINE configs[1] at full size (1M-particle dam break): the cell-list oracle finishes a step in a
+    fraction of a second, so the whole state is compared bit for bit after 3 steps, the neighbour counts
+    after the first density pass, and -- size-independent -- the ids must stay a permutation and every
+    particle inside the walls."""
+    params, a = scenes.dam_break(1024)
+    assert len(a) == 1 << 20
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.computeDensityPressure()
+        _, want_counts = O.density_cells(params, a.copy())
+        assert np.array_equal(s.neighbor_counts(), want_counts)
+        s.upload(a)
+        s.stepSimulation(nsteps=3)
+        got, ids = s.download(with_ids=True)
+    assert np.array_equal(np.sort(ids), np.arange(len(a)))
+    want = O.step_cells(params, a.copy(), 3)
+    assert orc.same_bits(got, want)
+    assert got["pos"][:, 0].min() >= params.xmin and got["pos"][:, 0].max() <= params.xmax
+    assert got["pos"][:, 1].min() >= params.ymin and got["pos"][:, 1].max() <= params.ymax
+
+
 def test_division_selftest():
     """exact_div.h (shared reciprocal + FMA corrections) against hipcc's correctly rounded `/`:
     every float of the safe range for 1/x, 2^31 random pairs for a/b.  Bar: zero mismatches."""
