@@ -216,6 +216,15 @@ def main():
                 traffic = json.load(open(tf)).get(name, {}).get("k_force_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu = None  # what actually bounds the kernel: VALU issue (PMC of the committed profile, informational)
+        try:
+            src = json.load(open(tf)).get(name, {}).get("source")
+            pm = json.load(open(os.path.join(ROOT, src)))
+            kf = [v for k, v in pm.items() if k.startswith("k_force<true")][0]
+            valu = {"busy_frac": kf.get("valu_busy_frac"), "lane_utilisation": kf.get("valu_lane_utilisation"),
+                    "wave_instructions_per_launch": kf.get("SQ_INSTS_VALU"), "source": src}
+        except Exception:
+            valu = None
         out = {
             "metric": "particle-updates/sec (full SPH step)",
             "value": value,
@@ -248,6 +257,7 @@ def main():
                 "traffic": traffic,
                 "avg_launch_ms": force_avg_s * 1e3,
                 "algorithmic_bytes_per_launch": FORCE_BYTES_PER_PARTICLE * n_local,
+                "valu": valu,
                 "note": "pair kernels are VALU-bound at ~50 neighbours (no MFMA: irregular gathers); see DESIGN.md",
             },
             "phases_ms_per_step": {k: v[0] / 5 for k, v in breakdown.items()},
