@@ -13,7 +13,7 @@
 //
 // Work decomposition: one workgroup per tile = `tile_cells` consecutive cells of one grid column.
 // With column-major keys the tile's particles are one contiguous slot range (coalesced SoA loads);
-// its neighbour candidates (three columns, rows +-1) are staged once in LDS as SoA records in
+// its neighbour candidates (three columns, rows +-1) are staged once in LDS in
 // row-major cell order, which makes every particle's 3x3 stencil one contiguous LDS range.  Lanes of
 // one cell scan the same LDS addresses (broadcast).  If a tile's candidates exceed the LDS budget
 // the same sums read global memory instead.
@@ -31,7 +31,7 @@
 //
 // All LDS of the pair kernels is one dynamic array (16-byte aligned base, no static __shared__ in
 // front of it): [PairRec rec[cap]] (force) or [float2 pos[cap]] (density) [int off[MAXC+1]] [int gs[MAXC]]
-// [int wave_tmp[4]] [int tile[4]] [u8 queue[QCAP*256] | u32 masks[8*256]] (force only).
+// [int wave_tmp[8]] [u8 queue[QCAP*256] | u32 masks[8*256]] (force only).
 // ---------------------------------------------------------------------------------------------
 constexpr int PAIR_MAXC = 3 * (PAIR_MAX_TILE_CELLS + 2);  // candidate cells of a tile (<= 256)
 #ifndef FORCE_Q
@@ -66,7 +66,7 @@ struct TileGeom {
 };
 
 static size_t pair_lds_bytes(int cap, bool force, int threads) {
-    size_t b = sizeof(int) * (2 * PAIR_MAXC + 1 + 4 + 4);  // off, gs, wave_tmp, queue slot
+    size_t b = sizeof(int) * (2 * PAIR_MAXC + 1 + 8);  // off, gs, wave_tmp
     // (the scan path's byte queue and the mask path's mask words share one region)
     const size_t qbytes = sizeof(uint8_t) * FORCE_QCAP * threads, mbytes = sizeof(uint32_t) * PAIR_MASK_WORDS * threads;
     b += force ? sizeof(PairRec) * (size_t)cap + (qbytes > mbytes ? qbytes : mbytes) : sizeof(float2) * (size_t)cap;
@@ -97,12 +97,13 @@ __device__ __forceinline__ int wg_excl_scan(int v, int* lds_wave, int& total, in
     return off + incl - v;
 }
 
-// Fills g, s_off[0..ncells] (LDS start of every candidate cell, row-major, PAIR_ROW_PAD sentinel slots
-// after every third cell) and s_gs[0..ncells) (global slot start of every candidate cell).
-// Returns false for an empty tile (uniform).
 __device__ __forceinline__ int cand_count(const int* s_off, int cc) {  // real particles of candidate cell cc
     return s_off[cc + 1] - s_off[cc] - ((cc % 3) == 2 ? PAIR_ROW_PAD : 0);
 }
+
+// Fills g, s_off[0..ncells] (LDS start of every candidate cell, row-major, PAIR_ROW_PAD sentinel slots
+// after every third cell) and s_gs[0..ncells) (global slot start of every candidate cell).
+// Returns false for an empty tile (uniform).
 
 template <int THREADS>
 __device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __restrict__ cell_start, int col, int trow,
