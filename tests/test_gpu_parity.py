@@ -337,3 +337,27 @@ def test_division_selftest():
     lib.check(L.sphhip_selftest_division(0, checked, bad))
     assert checked[0] > 1.3e9 and checked[1] >= 1 << 30
     assert list(bad)[:7] == [0] * 7  # [5], [6]: the rsq-based square root and the divisions by it
+
+
+def test_error_behaviour():
+    """Errors come back as negative codes with a message (never exit(), contrast SPH/sph.cuh:17-23) and leave
+    the context usable: capacity overflow, calls without particles, diagnostics without their pass."""
+    from sph_amd import lib
+
+    with Solver(P, n_max=256) as s:
+        with pytest.raises(lib.SphHipError, match="-3"):  # ESTATE: nothing uploaded
+            s.stepSimulation(nsteps=1)
+        with pytest.raises(lib.SphHipError, match="-4"):  # ECAPACITY
+            s.upload(scenes.lattice(257))
+        a = scenes.lattice(256)
+        s.upload(a)
+        with pytest.raises(lib.SphHipError, match="-3"):  # no grid yet
+            s.cells()
+        with pytest.raises(lib.SphHipError, match="-3"):  # no density pass yet
+            s.neighbor_counts()
+        with pytest.raises(lib.SphHipError, match="-1"):  # EINVAL
+            s.set_tuning(1000, 0)
+        with pytest.raises(lib.SphHipError, match="-1"):
+            s.stepSimulation(nsteps=-1)
+        s.stepSimulation(nsteps=2)  # still usable
+        assert orc.same_bits(s.download(), O.step_cells(P, a.copy(), 2))
