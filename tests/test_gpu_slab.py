@@ -54,11 +54,10 @@ def _worker(rank, world, port, nsteps, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_hip_slabs_equal_single_gpu(tmp_path, world):
+@pytest.mark.parametrize("world,nsteps", [(2, 30), (3, 30), (4, 90)])
+def test_hip_slabs_equal_single_gpu(tmp_path, world, nsteps):
     from sph_amd.solver import Solver
 
-    nsteps = 30
     out = str(tmp_path / "got.npy")
     mp.spawn(_worker, args=(world, _free_port(), nsteps, out), nprocs=world, join=True)
     got = np.load(out)
