@@ -489,6 +489,10 @@ extern "C" int sphhip_get_cells(SphCtx* c, int* keys, int* order, int* cell_star
         HIP_TRY(hipMemcpyAsync(cs.data(), c->cell_start, sizeof(int) * cs.size(), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!cs.empty() && c->tab_chi >= 0) {  // the table is maintained up to column tab_chi only: complete it
+        const size_t last = (size_t)c->tab_chi * c->dc.ny;
+        for (size_t k = last + 1; k < cs.size(); k++) cs[k] = cs[last];
+    }
     if (order)
         for (int i = 0; i < n; i++) order[i] = (int)(idv[i] & SPH_ID_MASK);
     if (cell_start) memcpy(cell_start, cs.data(), sizeof(int) * (size_t)c->ncell);
@@ -563,7 +567,6 @@ static_assert(sizeof(HaloRec) == 20, "halo record");
 // a kernel can read the old count and write the new one without a race); kernels read it
 // themselves and launches are sized by an upper bound (sph_n_grid).  The host value c->n is exact
 // only while c->n_exact; sph_sync_n reads it back (one stream synchronisation) when a caller needs it.
-enum { SPH_ERR_HALO_OVERFLOW = 1, SPH_ERR_MSG_BAD = 2, SPH_ERR_CAPACITY = 4 };
 
 static int* n_slot_next(SphCtx* c) { return sph_n_slot_next(c); }
 static void n_advance(SphCtx* c) { sph_n_advance(c); }
@@ -587,6 +590,7 @@ int sph_sync_n(SphCtx* c) {
         HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
         if (h[1] & SPH_ERR_CAPACITY) return fail(SPHHIP_ECAPACITY, "particle capacity of the context exceeded during asynchronous steps (particles were dropped)");
         if (h[1] & SPH_ERR_HALO_OVERFLOW) return fail(SPHHIP_ECAPACITY, "halo message buffer too small during asynchronous steps (records were dropped)");
+        if (h[1] & SPH_ERR_OUT_OF_SLAB) return fail(SPHHIP_ESTATE, "particles farther than the halo from the owned columns were found (and dropped) by a grid build");
         return fail(SPHHIP_ECAPACITY, "received halo message with a bad record count");
     }
     return SPHHIP_OK;

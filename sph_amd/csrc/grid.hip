@@ -312,7 +312,8 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
                                                        float2* __restrict__ vel_o, float* __restrict__ rho_o,
                                                        float* __restrict__ prs_o, uint32_t* __restrict__ idv_o,
                                                        int reorder_blocks, TileListArgs tl, int ny,
-                                                       int* __restrict__ zero_buf, int zero_words) {
+                                                       int* __restrict__ zero_buf, int zero_words,
+                                                       int* __restrict__ zero_buf2, int zero_words2) {
     if ((int)blockIdx.x >= reorder_blocks) {
         // tail workgroups: list the non-empty tiles of the pair kernels for this grid, and zero the idle
         // cell table for the next build -- two small launches saved per step
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
         sph_tile_list_thread(i, cell_start, ny, tl.tile_cells, tl.tiles_per_col, tl.col0, tl.ncols, tl.list, tl.count);
         const int stride = ((int)gridDim.x - reorder_blocks) * (int)blockDim.x;
         for (int k = i; k < zero_words; k += stride) zero_buf[k] = 0;
+        for (int k = i; k < zero_words2; k += stride) zero_buf2[k] = 0;
         return;
     }
     const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
@@ -358,7 +360,8 @@ __global__ __launch_bounds__(256) void k_cell_count(DevConsts c, const float2* _
                                                      uint32_t* __restrict__ rank, int* __restrict__ cell_cnt,
                                                      const int* __restrict__ prev_table,
                                                      const int* __restrict__ n_sorted, int drop_lo_cell,
-                                                     int drop_hi_cell) {
+                                                     int drop_hi_cell, int col_min, int col_max,
+                                                     int* __restrict__ err) {
     const int n = *d_n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i < n;
@@ -372,7 +375,12 @@ __global__ __launch_bounds__(256) void k_cell_count(DevConsts c, const float2* _
         float2 p = pos[i];
         int cx = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
         int cy = sph_cell_coord(p.y, c.ymin, c.inv_cell, c.ny);
-        key = (uint32_t)(cx * c.ny + cy);
+        if (cx < col_min || cx >= col_max) {  // outside the columns the cell table covers (a slab and its reach)
+            dead = true;
+            atomicOr(err, SPH_ERR_OUT_OF_SLAB);
+        } else {
+            key = (uint32_t)(cx * c.ny + cy);
+        }
     }
     const int lane = sph_lane_id();
     const uint32_t prev = __shfl_up(key, 1, 64);
@@ -497,9 +505,26 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     const int len = ncell + 1;
     const int nparts = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
     const int table_words = len + nparts;  // cell table + the partial sums of its scan
+    // The counting path maintains the table only for the columns that can hold particles: the owned
+    // columns, the halo and one more column on each side (what the tiles of the halo columns read).  On a
+    // slab of a wide global grid that is a fraction of the table.  Entries below the range stay 0; entries
+    // above it are never read by the kernels (sphhip_get_cells completes them on the host).
+    const int reach = SPHHIP_HALO_COLS + 1;
+    const int clo = c->col_lo - reach > 0 ? c->col_lo - reach : 0;
+    const int chi = c->col_hi + reach < c->dc.nx ? c->col_hi + reach : c->dc.nx;
+    const int r_first = clo * c->dc.ny;                       // first cell of the range
+    const int r_len = (chi - clo) * c->dc.ny + 1;             // cells of the range + the closing entry
+    const int r_parts = (r_len + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    bool range_moved = false;
     if (c->grid_counting) {
         {
             PhaseScope ps(c, SPHHIP_PH_HASH);
+            // the range moved (rebalance): the idle table is cleaned in full now, the current one (still needed
+            // by a pending ghost drop) in full after this build
+            range_moved = clo != c->tab_clo || chi != c->tab_chi;
+            if (range_moved) c->cell_next_zeroed = false;
+            c->tab_clo = clo;
+            c->tab_chi = chi;
             // switch to the idle cell table; it was zeroed by the previous build's reorder kernel
             const int next = 1 - c->cell_cur;
             if (!c->cell_next_zeroed) HIP_TRY(hipMemsetAsync(c->cell_buf[next], 0, sizeof(int) * (size_t)table_words, st));
@@ -510,7 +535,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             if (n > 0) {
                 hipLaunchKernelGGL(k_cell_count, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, c->d_n, c->keys2,
                                    c->perm2, c->cell_start, prev_table, c->counters + SPH_N_SORTED_SLOT,
-                                   c->slice_lo * c->dc.ny, c->slice_hi * c->dc.ny);
+                                   c->slice_lo * c->dc.ny, c->slice_hi * c->dc.ny, clo, chi, c->d_err);
                 LAUNCH_CHECK();
             }
         }
@@ -518,8 +543,9 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             PhaseScope ps(c, SPHHIP_PH_CELLS);
             // (the chunk sums are a kernel of their own: accumulating them with atomics in k_cell_count puts
             // thousands of atomics on a few hundred addresses, 0.4 us each -- measured 0.1 ms)
-            hipLaunchKernelGGL(k_scan_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->cell_start + len);
-            hipLaunchKernelGGL(k_scan_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->cell_start + len,
+            hipLaunchKernelGGL(k_scan_reduce, dim3(r_parts), dim3(256), 0, st, c->cell_start + r_first, r_len,
+                               c->cell_start + len);
+            hipLaunchKernelGGL(k_scan_apply, dim3(r_parts), dim3(256), 0, st, c->cell_start + r_first, r_len, c->cell_start + len,
                                c->counters + SPH_TILE_COUNT_SLOT, c->counters + SPH_N_SORTED_SLOT,
                                c->pending_drop ? sph_n_slot_next(c) : (int*)nullptr);
             LAUNCH_CHECK();
@@ -570,6 +596,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
         {
             PhaseScope ps(c, SPHHIP_PH_CELLS);
             c->cell_next_zeroed = false;  // (this path leaves both tables dirty)
+            c->tab_clo = c->tab_chi = -1;
             HIP_TRY(hipMemsetAsync(c->cell_start, 0x7f, sizeof(int) * (size_t)len, st));
             if (n > 0) {
                 hipLaunchKernelGGL(k_cell_marks, dim3((n + 255) / 256), dim3(256), 0, st, c->keys, c->perm, c->idv, c->d_n,
@@ -596,12 +623,15 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
         if (carry_density)
             hipLaunchKernelGGL(k_rank_reorder<true>, dim3(nb + tail), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
                                c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
-                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf, table_words);
+                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf + r_first, r_len, zero_buf + len, r_parts);
         else
             hipLaunchKernelGGL(k_rank_reorder<false>, dim3(nb + tail), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
                                c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
-                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf, table_words);
+                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf + r_first, r_len, zero_buf + len, r_parts);
         LAUNCH_CHECK();
+        if (tail > 0 && range_moved) {  // the tail zeroed only the new range of the old table
+            HIP_TRY(hipMemsetAsync(zero_buf, 0, sizeof(int) * (size_t)table_words, st));
+        }
         if (tail > 0) {
             c->cell_next_zeroed = true;
             c->tiles_valid = true;

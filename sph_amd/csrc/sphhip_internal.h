@@ -88,6 +88,7 @@ struct SphCtx {
     int* cell_buf[2] = {nullptr, nullptr};       // two cell tables (+ scan partials): the idle one is zeroed ahead
     int cell_cur = 0;
     bool cell_next_zeroed = false;               // cell_buf[1 - cell_cur] is all zero
+    int tab_clo = -1, tab_chi = -1;              // grid columns the cell tables are maintained for (slab + reach)
     int* block_hist = nullptr;                   // SORT_RADIX * nblocks
     int* digit_total = nullptr;                  // SORT_RADIX (+ SORT_RADIX bases)
     int* scan_tmp = nullptr;                     // block partials of the suffix-min scan
@@ -194,6 +195,9 @@ struct TileListArgs {
     int* list;
     int* count;
 };
+
+// sticky error bits of asynchronous steps (SphCtx::d_err)
+enum { SPH_ERR_HALO_OVERFLOW = 1, SPH_ERR_MSG_BAD = 2, SPH_ERR_CAPACITY = 4, SPH_ERR_OUT_OF_SLAB = 8 };
 
 constexpr int SPH_TILE_COUNT_SLOT = 56;  // SphCtx::counters[56]: number of listed tiles
 constexpr int SPH_N_SORTED_SLOT = 57;    // counters[57]: particle count after the last grid build
