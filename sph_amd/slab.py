@@ -138,6 +138,7 @@ class SlabSolver:
         # gloo cannot send CUDA tensors: stage the messages through host memory (tests / debugging);
         # under nccl (RCCL) the device buffers go straight over xGMI
         self.stage_cpu = dist.get_backend(group) == "gloo"
+        self._ops_cache = {}
         self.set_bounds(bounds)
 
     # -- partition ----------------------------------------------------------------------------
@@ -172,13 +173,19 @@ class SlabSolver:
             right = right.cpu() if right is not None else None
             recv_l = torch.empty(recv_l.shape, dtype=recv_l.dtype) if left is not None else None
             recv_r = torch.empty(recv_r.shape, dtype=recv_r.dtype) if right is not None else None
-        ops = []
-        if left is not None:
-            ops += [dist.P2POp(dist.isend, left, self._peer(r - 1), self.group),
-                    dist.P2POp(dist.irecv, recv_l, self._peer(r - 1), self.group)]
-        if right is not None:
-            ops += [dist.P2POp(dist.isend, right, self._peer(r + 1), self.group),
-                    dist.P2POp(dist.irecv, recv_r, self._peer(r + 1), self.group)]
+        # (the backend's message buffers are fixed: the op list is built once and reused every step)
+        key = tuple(t.data_ptr() if t is not None else 0 for t in (left, right, recv_l, recv_r))
+        ops = self._ops_cache.get(key) if not stage else None
+        if ops is None:
+            ops = []
+            if left is not None:
+                ops += [dist.P2POp(dist.isend, left, self._peer(r - 1), self.group),
+                        dist.P2POp(dist.irecv, recv_l, self._peer(r - 1), self.group)]
+            if right is not None:
+                ops += [dist.P2POp(dist.isend, right, self._peer(r + 1), self.group),
+                        dist.P2POp(dist.irecv, recv_r, self._peer(r + 1), self.group)]
+            if not stage:
+                self._ops_cache = {key: ops}
         if ops:
             for q in dist.batch_isend_irecv(ops):
                 q.wait()
