@@ -106,11 +106,11 @@ __device__ __forceinline__ int cand_count(const int* s_off, int cc) {  // real p
 // Returns false for an empty tile (uniform).
 
 template <int THREADS>
-__device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __restrict__ cell_start, int col, int trow,
-                                           int tile_cells, TileGeom& g, int* s_off, int* s_gs, int* s_wave, int tix) {
+__device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __restrict__ cell_start, int col, int cy0,
+                                           int cy1, TileGeom& g, int* s_off, int* s_gs, int* s_wave, int tix) {
     g.col = col;
-    g.cy0 = trow * tile_cells;
-    g.cy1 = min(g.cy0 + tile_cells, c.ny);
+    g.cy0 = cy0;
+    g.cy1 = cy1;
     g.ylo = max(g.cy0 - 1, 0);
     g.yhi = min(g.cy1 + 1, c.ny);
     // (all cell_start loads of the tile are issued together: one memory round trip; tiles come from the
@@ -137,6 +137,22 @@ __device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __rest
     }
     if (t == 0) s_off[g.ncells] = g.total;
     return g.own_lo != g.own_hi;
+}
+
+// Sets up rows [a, a + h) of a tile, halving h until the candidates fit the LDS budget (or h == 1): a
+// tile in a compressed region is processed as a few shorter sub-tiles through the LDS path instead of
+// falling back to global memory as a whole.  Uniform over the workgroup; k_density and k_force take the
+// same decisions (same table, same budget), so the masks of one describe the LDS image of the other.
+template <int THREADS>
+__device__ __forceinline__ bool tile_setup_fit(const DevConsts& c, const int* __restrict__ cell_start, int col, int a,
+                                               int& h, int cap, TileGeom& g, int* s_off, int* s_gs, int* s_wave,
+                                               int tix) {
+    for (;;) {
+        const bool nonempty = tile_setup<THREADS>(c, cell_start, col, a, a + h, g, s_off, s_gs, s_wave, tix);
+        if (g.total <= cap || h == 1) return nonempty;
+        h = (h + 1) >> 1;
+        __syncthreads();  // everyone is done with this attempt's tables
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -215,14 +231,12 @@ __device__ __forceinline__ void for_each_tile(const TileQueue& q, Body&& body) {
 }
 
 template <int THREADS>
-__device__ __forceinline__ void density_tile(const DevConsts& c, const float2* __restrict__ pos,
+__device__ __forceinline__ void density_rows(const DevConsts& c, const float2* __restrict__ pos,
                                              const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
                                              float* __restrict__ rho, float* __restrict__ prs,
                                              int* __restrict__ ncount, uint32_t* __restrict__ nmask, int n_max,
-                                             int col, int trow, int tile_cells, int cap, float2* s_pos, int* s_off,
-                                             int* s_gs, int* s_wave, int tix) {
-    TileGeom g;
-    if (!tile_setup<THREADS>(c, cell_start, col, trow, tile_cells, g, s_off, s_gs, s_wave, tix)) return;
+                                             const TileGeom& g, int cap, float2* s_pos, int* s_off, int* s_gs,
+                                             int tix) {
     // the first batch of own particles is fetched now, so that the loads overlap the staging below
     float2 pi0 = make_float2(0.0f, 0.0f);
     uint32_t key0 = 0;
@@ -302,6 +316,25 @@ __device__ __forceinline__ void density_tile(const DevConsts& c, const float2* _
         rho[s] = dens;
         prs[s] = pr;
         ncount[s] = cnt;
+    }
+}
+
+template <int THREADS>
+__device__ __forceinline__ void density_tile(const DevConsts& c, const float2* __restrict__ pos,
+                                             const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
+                                             float* __restrict__ rho, float* __restrict__ prs,
+                                             int* __restrict__ ncount, uint32_t* __restrict__ nmask, int n_max,
+                                             int col, int trow, int tile_cells, int cap, float2* s_pos, int* s_off,
+                                             int* s_gs, int* s_wave, int tix) {
+    const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
+    for (int a = cy0; a < cy1;) {  // (more than one trip only in a compressed region)
+        int h = cy1 - a;
+        TileGeom g;
+        asm volatile("" : "+v"(tix));  // keep thread-index arithmetic inside the loop, see for_each_tile
+        if (tile_setup_fit<THREADS>(c, cell_start, col, a, h, cap, g, s_off, s_gs, s_wave, tix))
+            density_rows<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, g, cap, s_pos, s_off, s_gs, tix);
+        a += h;
+        if (a < cy1) __syncthreads();  // the next sub-tile reuses the LDS image
     }
 }
 
@@ -690,27 +723,13 @@ struct OwnParticle {
 };
 
 template <bool FUSE, int THREADS>
-__device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __restrict__ pos,
+__device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __restrict__ pos,
                                            const float2* __restrict__ vel, const float* __restrict__ rho,
                                            const float* __restrict__ prs, const uint32_t* __restrict__ idv,
-                                           const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
-                                           float2* __restrict__ pos_o, float2* __restrict__ vel_o, int col, int trow,
-                                           int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my,
+                                           const uint32_t* __restrict__ skeys, float2* __restrict__ pos_o,
+                                           float2* __restrict__ vel_o, const TileGeom& g, int cap, float mx, float my,
                                            float strength, int allow_fast, const uint32_t* __restrict__ nmask,
-                                           int n_max, PairRec* s_rec, int* s_off, int* s_gs, int* s_wave,
-                                           uint8_t* s_q, int tix) {
-    // ghost column of a slab: pass the particles through (cheap test before any setup)
-    if (col < own_lo_col || col >= own_hi_col) {
-        int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
-        int lo = cell_start[col * c.ny + cy0], hi = cell_start[col * c.ny + cy1];
-        for (int s = lo + tix; s < hi; s += THREADS) {
-            vel_o[s] = vel[s];
-            if (FUSE) pos_o[s] = pos[s];
-        }
-        return;
-    }
-    TileGeom g;
-    if (!tile_setup<THREADS>(c, cell_start, col, trow, tile_cells, g, s_off, s_gs, s_wave, tix)) return;
+                                           int n_max, PairRec* s_rec, int* s_off, int* s_gs, uint8_t* s_q, int tix) {
     // the first batch of own particles is fetched now, so that the loads overlap the staging below
     OwnParticle own0;
     own0.load(g.own_lo + tix, g.own_lo + tix < g.own_hi, pos, vel, rho, prs, idv, skeys);
@@ -858,6 +877,39 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
         }
     }
 }
+
+template <bool FUSE, int THREADS>
+__device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __restrict__ pos,
+                                           const float2* __restrict__ vel, const float* __restrict__ rho,
+                                           const float* __restrict__ prs, const uint32_t* __restrict__ idv,
+                                           const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
+                                           float2* __restrict__ pos_o, float2* __restrict__ vel_o, int col, int trow,
+                                           int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my,
+                                           float strength, int allow_fast, const uint32_t* __restrict__ nmask,
+                                           int n_max, PairRec* s_rec, int* s_off, int* s_gs, int* s_wave,
+                                           uint8_t* s_q, int tix) {
+    const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
+    // ghost column of a slab: pass the particles through (cheap test before any setup)
+    if (col < own_lo_col || col >= own_hi_col) {
+        int lo = cell_start[col * c.ny + cy0], hi = cell_start[col * c.ny + cy1];
+        for (int s = lo + tix; s < hi; s += THREADS) {
+            vel_o[s] = vel[s];
+            if (FUSE) pos_o[s] = pos[s];
+        }
+        return;
+    }
+    for (int a = cy0; a < cy1;) {  // (more than one trip only in a compressed region; same sub-tiles as k_density)
+        int h = cy1 - a;
+        TileGeom g;
+        asm volatile("" : "+v"(tix));  // see density_tile
+        if (tile_setup_fit<THREADS>(c, cell_start, col, a, h, cap, g, s_off, s_gs, s_wave, tix))
+            force_rows<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, pos_o, vel_o, g, cap, mx, my, strength, allow_fast,
+                                      nmask, n_max, s_rec, s_off, s_gs, s_q, tix);
+        a += h;
+        if (a < cy1) __syncthreads();  // the next sub-tile reuses the LDS image
+    }
+}
+
 
 template <bool FUSE, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_WAVES_MAX, FORCE_WAVES_MAX))) void k_force(
