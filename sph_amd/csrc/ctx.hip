@@ -34,14 +34,14 @@ void sph_phase_begin(SphCtx* c, int ph) {
         t.start[ph].push_back(a);
         t.stop[ph].push_back(b);
     }
-    hipEventRecord(t.start[ph][t.used[ph]], c->stream);
+    (void)hipEventRecord(t.start[ph][t.used[ph]], c->stream);  // timing only: a failure shows up as a missing sample
 }
 
 void sph_phase_end(SphCtx* c, int ph) {
     if (!c->profiling || !((c->profile_mask >> ph) & 1u)) return;
     PhaseTimer& t = c->timer;
     if (t.used[ph] >= t.stop[ph].size()) return;
-    hipEventRecord(t.stop[ph][t.used[ph]], c->stream);
+    (void)hipEventRecord(t.stop[ph][t.used[ph]], c->stream);
     t.used[ph]++;
 }
 
