@@ -149,7 +149,7 @@ static hipError_t dmalloc(T** p, size_t count) {
 static void free_all(SphCtx* c) {
     void* ptrs[] = {c->pos, c->vel, c->pos2, c->vel2, c->rho, c->prs, c->rho2, c->prs2, c->idv, c->idv2,
                     c->ncount, c->nmask, c->keys, c->keys2, c->perm, c->perm2, c->ids_sorted, c->cell_buf[0], c->cell_buf[1], c->block_hist,
-                    c->digit_total, c->scan_tmp, c->counters, c->tile_list, c->staging};
+                    c->digit_total, c->scan_tmp, c->counters, c->tile_list, c->staging, c->dense_list};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int ph = 0; ph < SPHHIP_PH_COUNT; ph++) {
@@ -157,6 +157,7 @@ static void free_all(SphCtx* c) {
         for (hipEvent_t e : c->timer.stop[ph]) (void)hipEventDestroy(e);
     }
     if (c->h_host_tiles) (void)hipHostFree(c->h_host_tiles);
+    if (c->h_dense) (void)hipHostFree(c->h_dense);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 }
 
@@ -181,7 +182,10 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     c->col_hi = d.nx;
     if (const char* e = getenv("SPHHIP_TILE_CELLS")) {
         int v = atoi(e);
-        if (v >= 1 && v <= PAIR_MAX_TILE_CELLS) c->tile_cells = v;
+        if (v >= 1 && v <= PAIR_MAX_TILE_CELLS) {
+            c->tile_cells = c->tile_cells_max = v;
+            c->tile_cells_auto = false;
+        }
     }
     {   // exact_div.h needs every numerator of the pair force inside its safe range
         // inside [SPH_SAFE_LO, SPH_SAFE_HI] of exact_div.h with margin
@@ -230,12 +234,23 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     ok(dmalloc(&c->scan_tmp, (size_t)(c->ncell + 1 + 2047) / 2048 + 1));
     ok(dmalloc(&c->counters, 64));
     ok(dmalloc(&c->tile_list, (size_t)c->ncell + c->ncell / 64 + 64));
-    ok(hipHostMalloc((void**)&c->h_host_tiles, sizeof(int), hipHostMallocMapped));
+    ok(hipHostMalloc((void**)&c->h_host_tiles, 2 * sizeof(int), hipHostMallocMapped));
     if (e == hipSuccess) {
-        *c->h_host_tiles = -1;
+        c->h_host_tiles[0] = -1;
+        c->h_host_tiles[1] = 0;
         ok(hipHostGetDevicePointer((void**)&c->d_host_tiles, c->h_host_tiles, 0));
     }
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->num_cus = v; }
+    // a dense sub-tile holds more candidates than the smallest LDS budget (64 records, 9 of them sentinels) and
+    // a particle is a candidate of at most 9 one-row sub-tiles; one entry per sub-tile and DENSE_THREADS own
+    // particles: 9 n / 55 + n / 256 < n / 4 entries cover it
+    c->dense_cap = n_max / 4 + 64;
+    ok(hipMalloc((void**)&c->dense_list, sizeof(int4) * (size_t)c->dense_cap));
+    ok(hipHostMalloc((void**)&c->h_dense, 2 * sizeof(int), hipHostMallocMapped));
+    if (e == hipSuccess) {
+        c->h_dense[0] = c->h_dense[1] = -1;
+        ok(hipHostGetDevicePointer((void**)&c->d_dense, c->h_dense, 0));
+    }
     if (e == hipSuccess) ok(hipMemset(c->counters, 0, sizeof(int) * 64));
     c->d_err = c->counters + 16;
     c->n_ring = c->counters + 32;
@@ -291,7 +306,8 @@ extern "C" int sphhip_set_tuning(SphCtx* c, int tile_cells, int pair_cap) {
     if (!c) return fail(SPHHIP_EINVAL, "null context");
     if (tile_cells > 0) {
         if (tile_cells > PAIR_MAX_TILE_CELLS) return fail(SPHHIP_EINVAL, "tile_cells too large");
-        c->tile_cells = tile_cells;
+        c->tile_cells = c->tile_cells_max = tile_cells;
+        c->tile_cells_auto = false;
     }
     if (3 * (c->tile_cells + 2) > c->pair_threads) c->pair_threads = 256;  // one thread per candidate cell
     if (pair_cap > 0) {

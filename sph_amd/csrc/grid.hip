@@ -500,6 +500,7 @@ static inline int ilog2_ceil(unsigned v) {
 
 int sph_grid_build(SphCtx* c, bool carry_density) {
     const int n = sph_n_grid(c);  // exact count, or the capacity while the count is only known on the device
+    sph_adapt_tile_cells(c, n);
     hipStream_t st = c->stream;
     const int ncell = c->ncell;
     const int len = ncell + 1;

@@ -203,8 +203,8 @@ __device__ __forceinline__ void density_acc_mask(const DevConsts& c, float2 pi, 
 struct TileQueue {
     const int* list;   // compacted tile ids
     const int* count;  // number of entries
-    int* host_count;   // mapped host memory: the count, for sizing later launches
-    int tiles_per_col;
+    int* host_count;   // mapped host memory: the count and the tiling it belongs to, for sizing later launches
+    int tiles_per_col, tile_cells;
 };
 
 // Workgroup b takes entry (b & 7) * gridDim/8 + (b >> 3), then strides by gridDim: chunk b & 7 of the
@@ -217,7 +217,10 @@ __device__ __forceinline__ void for_each_tile(const TileQueue& q, Body&& body) {
     const int total = *q.count;
     int t = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     int tile = q.list[t];  // (the list is allocated for every t a launch can produce)
-    if (blockIdx.x == 0 && threadIdx.x == 0) *(volatile int*)q.host_count = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ((volatile int*)q.host_count)[0] = total;
+        ((volatile int*)q.host_count)[1] = q.tile_cells;
+    }
     while (t < total) {
         const int t_next = t + (int)gridDim.x;
         const int tile_next = t_next < total ? q.list[t_next] : 0;
@@ -230,13 +233,55 @@ __device__ __forceinline__ void for_each_tile(const TileQueue& q, Body&& body) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense sub-tiles.  A sub-tile the LDS path cannot take -- its candidates exceed the budget even at one
+// row of cells, or (force pass) a stencil range is too long for the masks / byte queue: ~30+ particles
+// per cell, e.g. the reference's fixed 1.9 x 1.9 box with tens of thousands of particles -- is not
+// processed by the tile's workgroup.  It is appended to a list, one entry per DENSE_THREADS own
+// particles, and k_density_dense / k_force_dense, launched right after, give every entry a workgroup
+// of its own: the dense code stays out of the tuned kernels, and dense regions spread over the GPU
+// instead of serialising in the few workgroups whose tiles they fall into.
+// Whether the follow-up kernel is needed is only known on the device.  The host launches it (and
+// passes defer = 1) unless the last dense kernel reported an empty list through mapped host memory;
+// with defer = 0 a workgroup that does meet a dense sub-tile evaluates it in place from global memory
+// (slow, correct) and raises the mapped flag, so that a later launch defers again.
+// ---------------------------------------------------------------------------------------------
+constexpr int DENSE_THREADS = 256;
+
+struct DenseSink {
+    int4* list;      // (col, first row, rows, part)
+    int* count;
+    int capacity;
+    int* host_flag;  // mapped host memory
+    int* err;
+    int defer;
+};
+
+// true: the sub-tile went to the list (uniform over the workgroup).
+__device__ __forceinline__ bool dense_defer(const DenseSink& d, const TileGeom& g, int tix) {
+    if (tix == 0) {
+        if (!d.defer) {
+            *(volatile int*)d.host_flag = 1;
+        } else {
+            const int nparts = (g.own_hi - g.own_lo + DENSE_THREADS - 1) / DENSE_THREADS;
+            const int e = atomicAdd(d.count, nparts);
+            if (e + nparts <= d.capacity) {
+                for (int p = 0; p < nparts; p++) d.list[e + p] = make_int4(g.col, g.cy0, g.cy1 - g.cy0, p);
+            } else {
+                atomicOr(d.err, SPH_ERR_CAPACITY);
+            }
+        }
+    }
+    return d.defer != 0;
+}
+
 template <int THREADS>
 __device__ __forceinline__ void density_rows(const DevConsts& c, const float2* __restrict__ pos,
                                              const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
                                              float* __restrict__ rho, float* __restrict__ prs,
                                              int* __restrict__ ncount, uint32_t* __restrict__ nmask, int n_max,
-                                             const TileGeom& g, int cap, float2* s_pos, int* s_off, int* s_gs,
-                                             int tix) {
+                                             const TileGeom& g, int cap, const DenseSink& sink, float2* s_pos,
+                                             int* s_off, int* s_gs, int tix) {
     // the first batch of own particles is fetched now, so that the loads overlap the staging below
     float2 pi0 = make_float2(0.0f, 0.0f);
     uint32_t key0 = 0;
@@ -246,6 +291,7 @@ __device__ __forceinline__ void density_rows(const DevConsts& c, const float2* _
     }
     __syncthreads();
     const bool use_lds = g.total <= cap;
+    if (!use_lds && dense_defer(sink, g, tix)) return;
     if (use_lds) {
         // 16 lanes per candidate cell, 16 cells per pass, PAIR_STAGE_BATCH passes' loads in flight together
         for (int cc0 = tix >> 4; cc0 < g.ncells; cc0 += PAIR_STAGE_BATCH * (THREADS / 16)) {
@@ -324,15 +370,16 @@ __device__ __forceinline__ void density_tile(const DevConsts& c, const float2* _
                                              const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
                                              float* __restrict__ rho, float* __restrict__ prs,
                                              int* __restrict__ ncount, uint32_t* __restrict__ nmask, int n_max,
-                                             int col, int trow, int tile_cells, int cap, float2* s_pos, int* s_off,
-                                             int* s_gs, int* s_wave, int tix) {
+                                             int col, int trow, int tile_cells, int cap, const DenseSink& sink,
+                                             float2* s_pos, int* s_off, int* s_gs, int* s_wave, int tix) {
     const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
     for (int a = cy0; a < cy1;) {  // (more than one trip only in a compressed region)
         int h = cy1 - a;
         TileGeom g;
         asm volatile("" : "+v"(tix));  // keep thread-index arithmetic inside the loop, see for_each_tile
         if (tile_setup_fit<THREADS>(c, cell_start, col, a, h, cap, g, s_off, s_gs, s_wave, tix))
-            density_rows<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, g, cap, s_pos, s_off, s_gs, tix);
+            density_rows<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, g, cap, sink, s_pos, s_off, s_gs,
+                                  tix);
         a += h;
         if (a < cy1) __syncthreads();  // the next sub-tile reuses the LDS image
     }
@@ -345,7 +392,7 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
                                                            float* __restrict__ rho, float* __restrict__ prs,
                                                            int* __restrict__ ncount, uint32_t* __restrict__ nmask,
                                                            int n_max, TileQueue q, int col_lo, int col_hi,
-                                                           int tile_cells, int cap) {
+                                                           int tile_cells, int cap, DenseSink sink) {
     extern __shared__ __align__(16) float4 s_dyn[];
     float2* s_pos = reinterpret_cast<float2*>(s_dyn);
     int* s_off = reinterpret_cast<int*>(s_pos + cap);
@@ -353,8 +400,8 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
     int* s_wave = s_gs + PAIR_MAXC;
     for_each_tile(q, [&](int col, int trow, int tix) {
         if (col < col_lo || col >= col_hi) return;  // (the list may cover the force pass's wider range)
-        density_tile<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, col, trow, tile_cells, cap, s_pos,
-                              s_off, s_gs, s_wave, tix);
+        density_tile<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, col, trow, tile_cells, cap, sink,
+                              s_pos, s_off, s_gs, s_wave, tix);
     });
 }
 
@@ -525,13 +572,17 @@ __device__ __forceinline__ void integrate_one(const DevConsts& c, float2& p, flo
 // ---------------------------------------------------------------------------------------------
 // Heavy phase of one round: evaluates the qn queued pairs of every lane (byte offsets from `lo` in
 // s_q), FORCE_HEAVY_UNROLL at a time, in queue order.
-template <int THREADS, bool FAST>
+template <int THREADS, bool FAST, bool WIN>
 __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s_rec,
                                             uint8_t* s_q, int qn, int lo, int self_off, float2 pi, float2 vi,
                                             float pres_i, float& fx, float& fy, int tix) {
     const int tid = tix;
+    // WIN: the range is one window of a longer one and the particle itself may lie outside it, so there is no
+    // +0 term to pad with: exhausted slots evaluate the window's first record and are left out of the sum.
+    if (!WIN) {
 #pragma unroll
-    for (int u = 0; u < FORCE_HEAVY_UNROLL - 1; u++) s_q[(qn + u) * THREADS + tid] = (uint8_t)self_off;
+        for (int u = 0; u < FORCE_HEAVY_UNROLL - 1; u++) s_q[(qn + u) * THREADS + tid] = (uint8_t)self_off;
+    }
     for (int t = 0; __any(t < qn); t += FORCE_HEAVY_UNROLL) {
         int jj[FORCE_HEAVY_UNROLL];
         float tx[FORCE_HEAVY_UNROLL], ty[FORCE_HEAVY_UNROLL];
@@ -541,7 +592,10 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
 #pragma unroll
         for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
             int e = s_q[(t + u) * THREADS + tid];
-            jj[u] = lo + ((t < qn) ? e : self_off);  // a lane whose queue is exhausted re-evaluates itself
+            if (WIN)
+                jj[u] = lo + ((t + u < qn) ? e : 0);
+            else
+                jj[u] = lo + ((t < qn) ? e : self_off);  // a lane whose queue is exhausted re-evaluates itself
         }
 #pragma unroll
         for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
@@ -557,7 +611,7 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
         // same order as the sequential sum: force += term(t); force += term(t+1); ...
 #pragma unroll
         for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
-            if (FAST) {
+            if (FAST && !WIN) {
                 fx += tx[u];
                 fy += ty[u];
             } else {
@@ -580,7 +634,7 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
 // +0, the pressure factor is finite because rho_i is in the safe range) and force + 0 == force --
 // and the queue tail is padded with the particle itself, so the accumulation needs no predicate.
 // !FAST keeps the reference's `j == i` test (sph.cpp:63) and a predicated accumulation.
-template <int THREADS, bool FAST>
+template <int THREADS, bool FAST, bool WIN = false>
 __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* s_rec,
                                              uint8_t* s_q, int j, int hi, int self, float2 pi, float2 vi,
                                              float pres_i, float& fx, float& fy, int tix) {
@@ -600,7 +654,8 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* 
                     float rx = pi.x - q[u].x, ry = pi.y - q[u].y;
                     float r2 = rx * rx + ry * ry;
                     bool in = !(r2 >= c.h2);  // sph.cpp:66
-                    if (!FAST) in = in && (j + u != self);  // sph.cpp:63
+                    if (!FAST || WIN) in = in && (j + u != self);  // sph.cpp:63
+                    if (WIN) in = in && (j + u < hi);  // (no sentinels behind a window: the range goes on)
                     // branch-free push: the slot is rewritten until a candidate is accepted
                     s_q[qn * THREADS + tid] = (uint8_t)(j + u - lo);
                     qn += in ? 1 : 0;
@@ -608,7 +663,7 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* 
                 j += FORCE_SCAN_UNROLL;
             }
         }
-        force_heavy<THREADS, FAST>(c, s_rec, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy, tix);
+        force_heavy<THREADS, FAST, WIN>(c, s_rec, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy, tix);
     }
 }
 
@@ -729,7 +784,8 @@ __device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __r
                                            const uint32_t* __restrict__ skeys, float2* __restrict__ pos_o,
                                            float2* __restrict__ vel_o, const TileGeom& g, int cap, float mx, float my,
                                            float strength, int allow_fast, const uint32_t* __restrict__ nmask,
-                                           int n_max, PairRec* s_rec, int* s_off, int* s_gs, uint8_t* s_q, int tix) {
+                                           int n_max, const DenseSink& sink, PairRec* s_rec, int* s_off, int* s_gs,
+                                           uint8_t* s_q, int tix) {
     // the first batch of own particles is fetched now, so that the loads overlap the staging below
     OwnParticle own0;
     own0.load(g.own_lo + tix, g.own_lo + tix < g.own_hi, pos, vel, rho, prs, idv, skeys);
@@ -752,6 +808,7 @@ __device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __r
         too_long = (s_off[3 * r1 + 3] - PAIR_ROW_PAD - s_off[3 * r0]) > FORCE_MAX_RANGE;
     }
     const bool use_lds = !__syncthreads_or(too_long) && g.total <= cap;
+    if (!use_lds && dense_defer(sink, g, tix)) return;
     const float inf = __builtin_inff();
     bool fast = false, by_mask = false;
     if (use_lds) {
@@ -886,8 +943,8 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
                                            float2* __restrict__ pos_o, float2* __restrict__ vel_o, int col, int trow,
                                            int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my,
                                            float strength, int allow_fast, const uint32_t* __restrict__ nmask,
-                                           int n_max, PairRec* s_rec, int* s_off, int* s_gs, int* s_wave,
-                                           uint8_t* s_q, int tix) {
+                                           int n_max, const DenseSink& sink, PairRec* s_rec, int* s_off, int* s_gs,
+                                           int* s_wave, uint8_t* s_q, int tix) {
     const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
     // ghost column of a slab: pass the particles through (cheap test before any setup)
     if (col < own_lo_col || col >= own_hi_col) {
@@ -904,7 +961,7 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
         asm volatile("" : "+v"(tix));  // see density_tile
         if (tile_setup_fit<THREADS>(c, cell_start, col, a, h, cap, g, s_off, s_gs, s_wave, tix))
             force_rows<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, pos_o, vel_o, g, cap, mx, my, strength, allow_fast,
-                                      nmask, n_max, s_rec, s_off, s_gs, s_q, tix);
+                                      nmask, n_max, sink, s_rec, s_off, s_gs, s_q, tix);
         a += h;
         if (a < cy1) __syncthreads();  // the next sub-tile reuses the LDS image
     }
@@ -917,7 +974,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
     const float* __restrict__ prs, const uint32_t* __restrict__ idv, const uint32_t* __restrict__ skeys,
     const int* __restrict__ cell_start, float2* __restrict__ pos_o, float2* __restrict__ vel_o, TileQueue q, int col_lo,
     int col_hi, int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my, float strength,
-    int allow_fast, const uint32_t* __restrict__ nmask, int n_max) {
+    int allow_fast, const uint32_t* __restrict__ nmask, int n_max, DenseSink sink) {
     extern __shared__ __align__(16) float4 s_dyn[];
     PairRec* s_rec = reinterpret_cast<PairRec*>(s_dyn);
     int* s_off = reinterpret_cast<int*>(s_rec + cap);
@@ -927,8 +984,194 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
     for_each_tile(q, [&](int col, int trow, int tix) {
         if (col < col_lo || col >= col_hi) return;
         force_tile<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, col, trow, tile_cells, cap,
-                                  own_lo_col, own_hi_col, mx, my, strength, allow_fast, nmask, n_max, s_rec, s_off, s_gs,
-                                  s_wave, s_q, tix);
+                                  own_lo_col, own_hi_col, mx, my, strength, allow_fast, nmask, n_max, sink, s_rec, s_off,
+                                  s_gs, s_wave, s_q, tix);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// The dense sub-tiles (see DenseSink): one workgroup per list entry = up to DENSE_THREADS own particles
+// of rows [a, a + h) of a column.  The candidate sequence of the sub-tile (row-major, row sentinels, as
+// in the tuned kernels) goes through the LDS buffer in chunks, one after the other, and every particle
+// walks its part of each chunk: ascending chunks = the canonical order.
+// ---------------------------------------------------------------------------------------------
+struct DenseQueue {
+    const int4* list;
+    const int* count;
+    int capacity;
+    int* host_count;  // mapped host memory: the count, for the host's next decision and grid size
+};
+
+template <class Body>
+__device__ __forceinline__ void for_each_dense(const DenseQueue& q, Body&& body) {
+    const int total = min(*q.count, q.capacity);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *(volatile int*)q.host_count = total;
+    for (int e = blockIdx.x; e < total; e += gridDim.x) {
+        __syncthreads();  // the previous entry is done with the LDS image
+        body(q.list[e], (int)threadIdx.x);
+    }
+}
+
+// Calls put(dst, cc, k) for every real candidate (cell cc, k-th particle) whose position in the
+// candidate sequence lies in [base, base + len), dst = position - base, and pad(dst) for the sentinels.
+template <int THREADS, class Put, class Pad>
+__device__ __forceinline__ void dense_stage_chunk(const TileGeom& g, const int* s_off, int base, int len, int tix,
+                                                  Put&& put, Pad&& pad) {
+    for (int cc = tix >> 4; cc < g.ncells; cc += THREADS / 16) {  // 16 lanes per candidate cell
+        const int o = s_off[cc], n = cand_count(s_off, cc);
+        const int k0 = max(0, base - o), k1 = min(n, base + len - o);
+        for (int k = k0 + (tix & 15); k < k1; k += 16) put(o + k - base, cc, k);
+    }
+    for (int t = tix; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS) {
+        const int seq = s_off[3 * (t / PAIR_ROW_PAD) + 3] - PAIR_ROW_PAD + (t % PAIR_ROW_PAD);
+        if (seq >= base && seq < base + len) pad(seq - base);
+    }
+}
+
+__global__ __launch_bounds__(DENSE_THREADS) void k_density_dense(DevConsts c, const float2* __restrict__ pos,
+                                                                  const uint32_t* __restrict__ skeys,
+                                                                  const int* __restrict__ cell_start,
+                                                                  float* __restrict__ rho, float* __restrict__ prs,
+                                                                  int* __restrict__ ncount, DenseQueue q, int cap) {
+    constexpr int THREADS = DENSE_THREADS;
+    extern __shared__ __align__(16) float4 s_dyn[];
+    float2* s_pos = reinterpret_cast<float2*>(s_dyn);
+    int* s_off = reinterpret_cast<int*>(s_pos + cap);
+    int* s_gs = s_off + PAIR_MAXC + 1;
+    int* s_wave = s_gs + PAIR_MAXC;
+    for_each_dense(q, [&](int4 ent, int tix) {
+        TileGeom g;
+        tile_setup<THREADS>(c, cell_start, ent.x, ent.y, ent.y + ent.z, g, s_off, s_gs, s_wave, tix);
+        __syncthreads();
+        const int s = g.own_lo + ent.w * THREADS + tix;
+        const bool have = s < g.own_hi;
+        float2 pi = make_float2(0.0f, 0.0f);
+        int lo_seq = 0, hi_seq = 0;
+        if (have) {
+            pi = pos[s];
+            const int cy = (int)skeys[s] - g.col * c.ny;
+            const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
+            lo_seq = s_off[3 * r0];
+            hi_seq = s_off[3 * r1 + 3] - PAIR_ROW_PAD;
+        }
+        float dens = 0.0f;
+        int cnt = 0;
+        const float inf = __builtin_inff();
+        for (int base = 0; base < g.total; base += cap) {
+            if (base) __syncthreads();  // the previous chunk has been read
+            dense_stage_chunk<THREADS>(
+                g, s_off, base, cap, tix, [&](int dst, int cc, int k) { s_pos[dst] = pos[s_gs[cc] + k]; },
+                [&](int dst) { s_pos[dst] = make_float2(inf, inf); });
+            __syncthreads();
+            const int k0 = max(lo_seq, base), k1 = min(hi_seq, base + cap);
+            // eight candidates per trip, loads first: at one or two waves per SIMD the LDS latency is not hidden
+            for (int k = k0; k < k1; k += 8) {
+                float2 qv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) qv[u] = s_pos[min(k + u, k1 - 1) - base];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    density_acc(c, pi, k + u < k1 ? qv[u] : make_float2(inf, inf), dens, cnt);
+            }
+        }
+        if (have) {
+            float pr = c.stiffness * (dens - c.rest_density);  // sph.cpp:52-53
+            if (pr < 0.0f) pr = 0.0f;
+            rho[s] = dens;
+            prs[s] = pr;
+            ncount[s] = cnt;
+        }
+    });
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(DENSE_THREADS) void k_force_dense(
+    DevConsts c, const float2* __restrict__ pos, const float2* __restrict__ vel, const float* __restrict__ rho,
+    const float* __restrict__ prs, const uint32_t* __restrict__ idv, const uint32_t* __restrict__ skeys,
+    const int* __restrict__ cell_start, float2* __restrict__ pos_o, float2* __restrict__ vel_o, DenseQueue q, int cap,
+    float mx, float my, float strength, int allow_fast) {
+    constexpr int THREADS = DENSE_THREADS;
+    extern __shared__ __align__(16) float4 s_dyn[];
+    PairRec* s_rec = reinterpret_cast<PairRec*>(s_dyn);
+    int* s_off = reinterpret_cast<int*>(s_rec + cap);
+    int* s_gs = s_off + PAIR_MAXC + 1;
+    int* s_wave = s_gs + PAIR_MAXC;
+    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_wave + 8);
+    const int chunk_len = cap - FORCE_SCAN_UNROLL;  // (the scan reads a few records past its window)
+    for_each_dense(q, [&](int4 ent, int tix) {
+        TileGeom g;
+        tile_setup<THREADS>(c, cell_start, ent.x, ent.y, ent.y + ent.z, g, s_off, s_gs, s_wave, tix);
+        __syncthreads();
+        const int s = g.own_lo + ent.w * THREADS + tix;
+        const bool have = s < g.own_hi;
+        OwnParticle own;
+        own.load(s, have, pos, vel, rho, prs, idv, skeys);
+        float2 pi = own.p, vi = own.v;
+        const float dens_i = own.d, pres_i = own.pr;
+        const bool valid = have && !(own.idv & SPH_INVALID_BIT);
+        int self_seq = -1, lo_seq = 0, hi_seq = 0;  // positions in the candidate sequence
+        // exact_div.h only while every density / pressure seen so far is in its safe range (the particle's own
+        // record may only arrive with a later chunk, so its operands are checked here)
+        int unsafe = allow_fast ? 0 : 1;
+        if (valid) {  // sph.cpp:59: invalid particles get no force
+            const int cy = (int)own.key - g.col * c.ny;
+            const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
+            const int self_cell = 3 * (cy - g.ylo) + 1;
+            lo_seq = s_off[3 * r0];
+            hi_seq = s_off[3 * r1 + 3] - PAIR_ROW_PAD;
+            self_seq = s_off[self_cell] + (s - s_gs[self_cell]);
+            unsafe |= (dens_i == 0.0f || !sph_safe_operand(dens_i) || !sph_safe_operand(pres_i)) ? 1 : 0;
+        }
+        const float inf = __builtin_inff();
+        float fx = 0.0f, fy = 0.0f;
+        for (int base = 0; base < g.total; base += chunk_len) {
+            if (base) __syncthreads();  // the previous chunk has been read
+            dense_stage_chunk<THREADS>(
+                g, s_off, base, chunk_len, tix,
+                [&](int dst, int cc, int k) {
+                    const int j = s_gs[cc] + k;
+                    float2 qj = pos[j];
+                    const float2 w = vel[j];
+                    const float dj = rho[j], pj = prs[j];
+                    unsafe |= (dj == 0.0f || !sph_safe_operand(dj) || !sph_safe_operand(pj)) ? 1 : 0;
+                    // `!particles[j].valid` (sph.cpp:63): an invalid j sits at +inf, out of everyone's range
+                    if (idv[j] & SPH_INVALID_BIT) qj = make_float2(inf, inf);
+                    PairRec rec;
+                    rec.aux = make_float4(w.x, w.y, dj, pj);
+                    rec.pos = qj;
+                    rec.yd = sph_rcp_refined(dj);
+                    rec.pad = 0.0f;
+                    s_rec[dst] = rec;
+                },
+                [&](int dst) {
+                    PairRec rec;
+                    rec.aux = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+                    rec.pos = make_float2(inf, inf);
+                    rec.yd = 1.0f;
+                    rec.pad = 0.0f;
+                    s_rec[dst] = rec;
+                });
+            const bool fast = !__syncthreads_or(unsafe);
+            // the particle's part of this chunk, in windows the byte queue can address
+            const int k0 = max(lo_seq, base), k1 = min(hi_seq, base + chunk_len);
+            for (int w0 = k0; __any(w0 < k1); w0 += FORCE_MAX_RANGE) {
+                const int w1 = min(w0 + FORCE_MAX_RANGE, k1);
+                if (fast)
+                    force_rounds<THREADS, true, true>(c, s_rec, s_q, w0 - base, w1 - base, self_seq - base, pi, vi, pres_i,
+                                                      fx, fy, tix);
+                else
+                    force_rounds<THREADS, false, true>(c, s_rec, s_q, w0 - base, w1 - base, self_seq - base, pi, vi, pres_i,
+                                                       fx, fy, tix);
+            }
+        }
+        if (have) {
+            if (valid) {
+                force_epilogue<FUSE>(c, fx, fy, pi, vi, dens_i, mx, my, strength);
+                if (FUSE) integrate_one(c, pi, vi);
+            }
+            if (FUSE) pos_o[s] = pi;  // sph.cpp:59,103: invalid particles are left alone
+            vel_o[s] = vi;
+        }
     });
 }
 
@@ -1131,6 +1374,7 @@ static int ensure_tile_list(SphCtx* c, TileQueue& q) {
     q.count = tl.count;
     q.host_count = c->d_host_tiles;
     q.tiles_per_col = tl.tiles_per_col;
+    q.tile_cells = tl.tile_cells;
     return SPHHIP_OK;
 }
 
@@ -1138,9 +1382,11 @@ static int ensure_tile_list(SphCtx* c, TileQueue& q) {
 // (plus slack; the kernels stride, so an underestimate only costs balance), else one resident wave of
 // workgroups.  Always a multiple of 8 (one chunk per XCD).
 static int pair_grid(SphCtx* c, const void* kern, int threads, size_t lds, int& grid) {
-    const int est = *(volatile int*)c->h_host_tiles;
-    if (est >= 0) {
-        grid = (est + est / 128 + 8 + 7) & ~7;
+    const int est = ((volatile int*)c->h_host_tiles)[0], est_cells = ((volatile int*)c->h_host_tiles)[1];
+    if (est >= 0 && est_cells > 0) {
+        // (a count taken under another tiling is rescaled; any grid size is correct)
+        const long long e = est_cells == c->tile_cells ? est : ((long long)est * est_cells + c->tile_cells - 1) / c->tile_cells;
+        grid = (int)((e + e / 128 + 8 + 7) & ~7ll);
         return SPHHIP_OK;
     }
     int per_cu = 0;
@@ -1148,6 +1394,60 @@ static int pair_grid(SphCtx* c, const void* kern, int threads, size_t lds, int& 
     if (per_cu < 1) per_cu = 1;
     grid = (c->num_cus * per_cu) & ~7;
     if (grid < 8) grid = 8;
+    return SPHHIP_OK;
+}
+
+// Tile height for the coming grid build.  The tuned height (tile_cells_max cells) assumes a few hundred
+// candidates per tile.  In a dense scene (the reference's fixed 1.9 x 1.9 box with thousands of particles:
+// 25-100 per cell) such a tile overflows the LDS budget and the kernels cut it into sub-tiles that one
+// workgroup processes one after the other -- with only a few dozen tiles in the whole grid, most of the
+// GPU idles.  Going by the tile count the last launch reported (mapped host memory, so a step or two old)
+// the host then picks a smaller height: the sub-tiles become tiles of their own.  Only scenes that are
+// both overflowing and short of workgroups are touched; results do not depend on the tiling.
+void sph_adapt_tile_cells(SphCtx* c, int n) {
+    if (!c->tile_cells_auto) return;
+    const int tiles = ((volatile int*)c->h_host_tiles)[0], cells = ((volatile int*)c->h_host_tiles)[1];
+    if (tiles <= 0 || cells <= 0 || n <= 0) return;
+    // particles per cell of the listed tiles (a column's last tile may overhang the grid)
+    const int per_col = (c->dc.ny + cells - 1) / cells;
+    const double occ = (double)n / ((double)tiles * ((double)c->dc.ny / per_col));
+    auto cand = [&](int tc) { return occ * 3.0 * (tc + 2); };
+    int want = c->tile_cells;
+    const bool starved = (long long)tiles * cells < (long long)8 * c->num_cus * c->tile_cells;  // < 8 tiles per CU
+    if (starved && cand(want) > 0.9 * c->pair_cap) {
+        while (want > 1 && cand(want) > 0.9 * c->pair_cap) want--;
+    } else {
+        while (want < c->tile_cells_max && cand(want + 1) < 0.6 * c->pair_cap) want++;
+        if (want < c->tile_cells_max && want < c->tile_cells + 2) want = c->tile_cells;  // (no dithering)
+    }
+    if (want != c->tile_cells) {
+        c->tile_cells = want;
+        c->tiles_valid = false;
+    }
+}
+
+// Sink / queue of the dense sub-tiles for one pair-kernel launch (which: 0 density, 1 force) and the
+// decision whether the follow-up kernel runs: yes unless the last one reported an empty list (the
+// mapped ints start at -1 = unknown).
+static int dense_prepare(SphCtx* c, int which, DenseSink& sink, DenseQueue& dq, int& grid) {
+    const int seen = ((volatile int*)c->h_dense)[which];
+    int* count = c->counters + SPH_DENSE_COUNT_SLOT;
+    sink.list = c->dense_list;
+    sink.count = count;
+    sink.capacity = c->dense_cap;
+    sink.host_flag = c->d_dense + which;
+    sink.err = c->d_err;
+    sink.defer = seen != 0 ? 1 : 0;
+    dq.list = c->dense_list;
+    dq.count = count;
+    dq.capacity = c->dense_cap;
+    dq.host_count = c->d_dense + which;
+    grid = 0;
+    if (sink.defer) {
+        HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), c->stream));
+        const long long want = seen > 0 ? (long long)seen + seen / 8 + 8 : 0;
+        grid = (int)std::min<long long>(std::max<long long>(want, 2 * c->num_cus), 1 << 20);
+    }
     return SPHHIP_OK;
 }
 
@@ -1165,9 +1465,18 @@ int sph_density_launch(SphCtx* c) {
     auto kern = th == 128 ? k_density<128> : k_density<256>;
     int grid = 0;
     if ((rc = pair_grid(c, reinterpret_cast<const void*>(kern), th, lds, grid))) return rc;
+    DenseSink sink;
+    DenseQueue dq;
+    int dense_grid = 0;
+    if ((rc = dense_prepare(c, 0, sink, dq, dense_grid))) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, c->pos, c->keys, c->cell_start, c->rho,
-                       c->prs, c->ncount, c->nmask, c->n_max, q, lo, hi, c->tile_cells, c->pair_cap);
+                       c->prs, c->ncount, c->nmask, c->n_max, q, lo, hi, c->tile_cells, c->pair_cap, sink);
     LAUNCH_CHECK();
+    if (sink.defer) {
+        hipLaunchKernelGGL(k_density_dense, dim3(dense_grid), dim3(DENSE_THREADS), pair_lds_bytes(c->pair_cap, false, DENSE_THREADS),
+                           c->stream, c->dc, c->pos, c->keys, c->cell_start, c->rho, c->prs, c->ncount, dq, c->pair_cap);
+        LAUNCH_CHECK();
+    }
     c->counts_valid = true;
     c->mask_tile_cells = c->tile_cells;
     c->mask_cap = c->pair_cap;
@@ -1193,11 +1502,22 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
                                : (th == 128 ? k_force<false, 128> : k_force<false, 256>);
     int grid = 0;
     if ((rc = pair_grid(c, reinterpret_cast<const void*>(kern), th, lds, grid))) return rc;
+    DenseSink sink;
+    DenseQueue dq;
+    int dense_grid = 0;
+    if ((rc = dense_prepare(c, 1, sink, dq, dense_grid))) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv,
                        c->keys, c->cell_start, c->pos2, c->vel2, q, flo, fhi, c->tile_cells, c->pair_cap, c->col_lo,
                        c->col_hi, mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr,
-                       c->n_max);
+                       c->n_max, sink);
     LAUNCH_CHECK();
+    if (sink.defer) {
+        auto dkern = fuse_integrate ? k_force_dense<true> : k_force_dense<false>;
+        hipLaunchKernelGGL(dkern, dim3(dense_grid), dim3(DENSE_THREADS), pair_lds_bytes(c->pair_cap, true, DENSE_THREADS),
+                           c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv, c->keys, c->cell_start, c->pos2, c->vel2,
+                           dq, c->pair_cap, mx, my, strength, c->fast_div ? 1 : 0);
+        LAUNCH_CHECK();
+    }
     std::swap(c->vel, c->vel2);
     if (fuse_integrate) {
         std::swap(c->pos, c->pos2);

@@ -65,6 +65,8 @@ struct SphCtx {
     int slice_lo = 0, slice_hi = 0;
     int col_lo = 0, col_hi = 0;  // owned columns (default: all)
     int tile_cells = 12;         // cells of a column per pair-kernel workgroup
+    int tile_cells_max = 12;     // ... its upper bound; sph_adapt_tile_cells picks tile_cells below it for dense scenes
+    bool tile_cells_auto = true; // false once SPHHIP_TILE_CELLS / sphhip_set_tuning fixed the tiling
     int pair_cap = 960;          // neighbour candidates staged in LDS per workgroup (4 workgroups of k_force per CU)
     int pair_threads = 256;      // 128 or 256
     bool fast_div = true;        // exact_div.h allowed (constants in its safe range; SPHHIP_FAST_DIV=0 disables)         // neighbour candidates staged in LDS per workgroup
@@ -97,8 +99,12 @@ struct SphCtx {
     bool tiles_valid = false;                    // ... current for this grid, tiles_cells, [tiles_lo, tiles_hi)
     int tiles_cells = 0, tiles_lo = 0, tiles_hi = 0;
     int num_cus = 256;
-    int* h_host_tiles = nullptr;                 // mapped host int: tile count of a recent launch (-1: none yet)
+    int* h_host_tiles = nullptr;                 // mapped host ints: tile count of a recent launch (-1: none yet), its tile_cells
     int* d_host_tiles = nullptr;                 // its device address
+    int4* dense_list = nullptr;                  // dense sub-tiles of the running pair kernel (pairs.hip: DenseSink)
+    int dense_cap = 0;                           // its capacity in entries
+    int* h_dense = nullptr;                      // mapped host ints: entries of the last dense density / force kernel (-1: unknown)
+    int* d_dense = nullptr;                      // their device address
     void* staging = nullptr;                     // AoS staging for upload / download (28 B * n_max)
 
     bool profiling = false;
@@ -125,6 +131,7 @@ int sph_hip_fail(hipError_t e, const char* what, const char* file, int line);
 // ---- phase implementations (each enqueues on ctx->stream and returns) -----------------------
 int sph_grid_build(SphCtx* c, bool carry_density);
 int sph_density_launch(SphCtx* c);
+void sph_adapt_tile_cells(SphCtx* c, int n);  // pairs.hip: tile height for the coming grid build
 int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate);
 int sph_integrate_launch(SphCtx* c);
 int sph_step_reference_order(SphCtx* c, float mx, float my, float strength, int nsteps);
@@ -202,6 +209,7 @@ enum { SPH_ERR_HALO_OVERFLOW = 1, SPH_ERR_MSG_BAD = 2, SPH_ERR_CAPACITY = 4, SPH
 constexpr int SPH_TILE_COUNT_SLOT = 56;  // SphCtx::counters[56]: number of listed tiles
 constexpr int SPH_N_SORTED_SLOT = 57;    // counters[57]: particle count after the last grid build
 constexpr int SPH_MSG_COUNT_SLOT = 58;   // counters[58..59]: record counts of the halo messages being packed
+constexpr int SPH_DENSE_COUNT_SLOT = 61; // counters[61]: entries of the dense sub-tile list
 constexpr int SPH_MSG_TICKET_SLOT = 60;  // counters[60]: finished workgroups of the pack kernel
 
 // ring of device-side particle counts (see ctx.hip)

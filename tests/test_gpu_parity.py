@@ -302,6 +302,28 @@ def test_scaled_scene_miniatures():
         assert np.abs(got["pos"] - ref["pos"]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("n,cap,steps", [(8192, 0, 4), (8192, 200, 3), (16384, 0, 3), (16384, 448, 2)])
+def test_dense_reference_box_bit_exact(n, cap, steps):
+    """The reference's own scene at a large N (main.cpp's fixed 1.9 x 1.9 box: 50-100 particles per cell,
+    stencil ranges of 400-900 candidates): windows of long ranges, candidate sequences staged chunk by
+    chunk, and the tile height the host adapts after the first step must all keep every bit.  Neighbour
+    counts against the all-pairs predicate of the reference."""
+    a = scenes.lattice(n)
+    with Solver(P, n_max=n) as s:
+        if cap:
+            s.set_tuning(0, cap)
+        s.upload(a)
+        s.computeDensityPressure()
+        assert np.array_equal(s.neighbor_counts(), O.neighbor_counts_allpairs(P, a))
+        s.upload(a)
+        for _ in range(steps):  # (one call per step: the host sees the tile count of the step before)
+            s.stepSimulation(nsteps=1)
+            s.synchronize()
+        got = s.download()
+    want = O.step_cells(P, a.copy(), steps)
+    assert orc.same_bits(got, want)
+
+
 def test_full_size_dam_break_bit_exact():
     """BASELINE configs[1] at full size (1M-particle dam break): the cell-list oracle finishes a step in a
     fraction of a second, so the whole state is compared bit for bit after 3 steps, the neighbour counts
