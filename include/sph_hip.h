@@ -43,6 +43,20 @@ void hip_stepSimulation(std::vector<Particle>& particles, int N, float2 mousePos
 // nsteps steps with the state resident in HBM, one upload and one download.
 void hip_stepSimulationResident(std::vector<Particle>& particles, int N, float2 mousePos, float interactionStrength,
                                 int nsteps);
+// Device-flavour interface of the reference's CUDA variant (SPH/sph.cuh:37-39), same shapes with `void*` in
+// place of `cudaGraphicsResource*`.  The state lives on the GPU between the calls (the reference's hidden
+// `d_particles`, SPH/sph.cu:10); the caller's array is an output, refreshed by every call (sph.cu:204,235).
+//   hip_initSimulation(Particle*, N, vbo): initSimulation, sph.cu:166-205 -- lattice fill, upload, copy back.
+//   hip_stepSimulation(Particle*, N, grid, cellStart, cellEnd, vbo, mousePos, strength): stepSimulation,
+//     sph.cu:218-236 -- one step of the resident state (no upload), then the full download.  The three int
+//     arrays are dead parameters in the reference (always passed through as nullptr, sph.cu:222-223); here
+//     each may be nullptr or receive the neighbour search of the RETURNED state: grid[i] = cell key of
+//     particle i (N ints), cellStart/cellEnd = half-open sorted-slot range of every cell (nx*ny ints each).
+//   `vbo`: nullptr, or a host `float2[N]` that receives what updateVBO writes (sph.cu:207-216): the position
+//     of every valid particle, (-1, -1) for invalid ones.
+void hip_initSimulation(Particle* particles, int N, void* vbo);
+void hip_stepSimulation(Particle* particles, int N, int* grid, int* cellStart, int* cellEnd, void* vbo, float2 mousePos,
+                        float interactionStrength);
 // cleanupSimulation (SPH/sph.cu:275-280): releases the cached device context.
 void hip_cleanupSimulation();
 

@@ -14,6 +14,7 @@
 namespace {
 SphCtx* g_ctx = nullptr;
 int g_cap = 0;
+int g_resident = -1;  // particle count of the device-flavour interface's resident state (-1: none)
 std::string g_err;
 
 bool fail(const char* where, int rc) {
@@ -45,6 +46,7 @@ bool upload(std::vector<Particle>& v, int n) {
         return false;
     }
     if (!ensure_ctx(n)) return false;
+    g_resident = -1;  // the vector interface replaces whatever state was resident
     int rc = sphhip_upload(g_ctx, v.data(), n, 0);
     return rc ? fail("sphhip_upload", rc) : true;
 }
@@ -61,6 +63,7 @@ void hip_cleanupSimulation() {
     if (g_ctx) sphhip_destroy(g_ctx);
     g_ctx = nullptr;
     g_cap = 0;
+    g_resident = -1;
 }
 
 void hip_initSimulation(std::vector<Particle>& particles, int N) {
@@ -150,6 +153,75 @@ void hip_stepSimulationResident(std::vector<Particle>& particles, int N, float2 
 
 void hip_stepSimulation(std::vector<Particle>& particles, int N, float2 mousePos, float interactionStrength) {
     hip_stepSimulationResident(particles, N, mousePos, interactionStrength, 1);
+}
+
+// ---- device-flavour interface (SPH/sph.cuh:37-39) ---------------------------------------------
+namespace {
+void write_vbo(const Particle* particles, int N, void* vbo) {  // updateVBO, SPH/sph.cu:207-216
+    if (!vbo) return;
+    float2* out = static_cast<float2*>(vbo);
+    for (int i = 0; i < N; i++) out[i] = particles[i].valid ? particles[i].pos : float2(-1.0f, -1.0f);
+}
+}  // namespace
+
+void hip_initSimulation(Particle* particles, int N, void* vbo) {
+    if (!particles || N < 0) {
+        g_err = "hip_initSimulation: bad argument";
+        return;
+    }
+    std::vector<Particle> v;
+    hip_initSimulation(v, N);
+    if (N > 0) std::memcpy((void*)particles, (const void*)v.data(), sizeof(Particle) * (size_t)N);
+    if (!ensure_ctx(N)) return;
+    int rc = sphhip_upload(g_ctx, particles, N, 0);  // sph.cu:202
+    if (rc) {
+        fail("sphhip_upload", rc);
+        return;
+    }
+    g_resident = N;
+    write_vbo(particles, N, vbo);
+}
+
+void hip_stepSimulation(Particle* particles, int N, int* grid, int* cellStart, int* cellEnd, void* vbo, float2 mousePos,
+                        float interactionStrength) {
+    if (!particles || N < 0) {
+        g_err = "hip_stepSimulation: bad argument";
+        return;
+    }
+    if (g_resident != N) {  // no matching initSimulation before: adopt the caller's array as the state
+        if (!ensure_ctx(N)) return;
+        int rc = sphhip_upload(g_ctx, particles, N, 0);
+        if (rc) {
+            fail("sphhip_upload", rc);
+            return;
+        }
+        g_resident = N;
+    }
+    int rc = sphhip_step(g_ctx, mousePos.x, mousePos.y, interactionStrength, 1);  // sph.cu:222-225
+    if (rc) {
+        fail("sphhip_step", rc);
+        return;
+    }
+    rc = sphhip_download(g_ctx, particles, N);  // sph.cu:235
+    if (rc) {
+        fail("sphhip_download", rc);
+        return;
+    }
+    write_vbo(particles, N, vbo);
+    if (grid || cellStart || cellEnd) {
+        rc = sphhip_build_grid(g_ctx);
+        if (rc) {
+            fail("sphhip_build_grid", rc);
+            return;
+        }
+        std::vector<int> keys(grid ? N : 0), order(grid ? N : 0);
+        rc = sphhip_get_cells(g_ctx, grid ? keys.data() : nullptr, grid ? order.data() : nullptr, cellStart, cellEnd);
+        if (rc) {
+            fail("sphhip_get_cells", rc);
+            return;
+        }
+        for (int s = 0; grid && s < N; s++) grid[order[s]] = keys[s];
+    }
 }
 
 float HIP_performance_test(int N) {

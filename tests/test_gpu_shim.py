@@ -71,6 +71,30 @@ def test_cells_through_shim(tmp_path):
     assert np.array_equal(cs, ocs[:-1]) and np.array_equal(ce, ocs[1:])
 
 
+def test_device_flavour_interface(tmp_path):
+    """initSimulation / stepSimulation shapes of the CUDA variant (SPH/sph.cuh:37-39): resident state, host
+    array refreshed by every call, vbo contents of updateVBO, and the (in the reference dead) grid /
+    cellStart / cellEnd parameters describing the returned state."""
+    n, steps = 1024, 4
+    fout = drive(tmp_path, "device", None, n, steps, 1.0, 1.0, 50000.0)
+    raw = open(fout, "rb").read()
+    got = np.frombuffer(raw[:28 * n], PARTICLE_DTYPE)
+    rest = np.frombuffer(raw[28 * n:], np.int32)
+    grid, nc = rest[:n], int(rest[n])
+    cs, ce = rest[n + 1:n + 1 + nc], rest[n + 1 + nc:n + 1 + 2 * nc]
+    vbo = rest[n + 1 + 2 * nc:].view(np.float32).reshape(n, 2)
+    a = G("f1_init")["n1024"]
+    want = a.copy()
+    for _ in range(steps):
+        want = O.step_cells(P, want, 1, mouse=(1.0, 1.0), strength=50000.0)
+    assert orc.same_bits(got, want)
+    okeys, oorder, oskeys, ocs = O.build_cells(P, want)
+    assert nc == len(ocs) - 1
+    assert np.array_equal(grid, okeys)
+    assert np.array_equal(cs, ocs[:-1]) and np.array_equal(ce, ocs[1:])
+    assert np.array_equal(vbo.view(np.uint32), got["pos"].view(np.uint32))
+
+
 def test_headless_dispatcher(tmp_path):
     out = subprocess.run([CLI, "--n", "1024", "--mode", "perf"], capture_output=True, text=True, check=True,
                          timeout=300).stdout

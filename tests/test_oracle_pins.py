@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import orc
+from sph_amd import scenes
 from sph_amd.params import PARTICLE_DTYPE
 
 O = orc.Oracle()
@@ -182,3 +183,21 @@ def test_oracle_vs_compiled_reference_random_states():
                 assert orc.same_bits(x, y)
     for n in (1, 2, 3, 7, 64, 1023, 1025, 5000):
         assert orc.same_bits(R.init(n), O.init_lattice(n))
+
+
+def test_init_column_count_sqrt_double_vs_float():
+    """serial_initSimulation takes cols = (int)ceil(sqrt((double)N)) (sph.cpp:136), the MPI
+    flavour (int)ceil(sqrtf((float)N)) (MPI_sph.cpp:97).  They agree for every N <= 2^24 (checked here in
+    full); the first difference is N = 2^24 + 1 (not representable in binary32): 4097 vs 4096 columns.
+    This repo's init (scenes.lattice, hip_initSimulation) uses the serial form."""
+    step = 1 << 22
+    for lo in range(1, (1 << 24) + 1, step):
+        n = np.arange(lo, min(lo + step, (1 << 24) + 1), dtype=np.int64)
+        a = np.ceil(np.sqrt(n.astype(np.float64))).astype(np.int64)
+        b = np.ceil(np.sqrt(n.astype(np.float32))).astype(np.int64)
+        assert np.array_equal(a, b)
+    n = np.int64((1 << 24) + 1)
+    assert int(np.ceil(np.sqrt(np.float64(n)))) == 4097 and int(np.ceil(np.sqrt(np.float32(n)))) == 4096
+    a = scenes.lattice((1 << 24) + 1)  # the double form: 4097 columns
+    assert a["pos"][4096, 1] == a["pos"][0, 1] and a["pos"][4097, 1] < a["pos"][0, 1]
+
