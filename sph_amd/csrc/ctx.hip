@@ -158,6 +158,7 @@ static void free_all(SphCtx* c) {
     }
     if (c->h_host_tiles) (void)hipHostFree(c->h_host_tiles);
     if (c->h_dense) (void)hipHostFree(c->h_dense);
+    if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 }
 
@@ -197,6 +198,8 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
         if (const char* e = getenv("SPHHIP_FAST_DIV")) c->fast_div = c->fast_div && atoi(e) != 0;
     }
     if (const char* e = getenv("SPHHIP_USE_MASKS")) c->use_masks = atoi(e) != 0;
+    if (const char* e = getenv("SPHHIP_GRAPH")) c->graph_off = atoi(e) == 0;
+    if (const char* e = getenv("SPHHIP_SMALL_GRID")) c->small_grid = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_LAZY_PACK")) c->lazy_pack = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_GRID")) c->grid_counting = std::string(e) != "radix";
     if (const char* e = getenv("SPHHIP_PAIR_THREADS")) {
@@ -468,15 +471,115 @@ extern "C" int sphhip_integrate(SphCtx* c) {
     return sph_integrate_launch(c);
 }
 
+static int step_once(SphCtx* c, float mx, float my, float strength) {
+    int rc = sph_grid_build(c, false);
+    if (rc) return rc;
+    rc = sph_density_launch(c);
+    if (rc) return rc;
+    return sph_force_launch(c, mx, my, strength, true);
+}
+
+// ---- graph replay of small scenes -----------------------------------------------------------
+// A step is 7 launches.  Below ~100 k particles they take less time on the GPU than the host needs to
+// enqueue them (N = 1024, the reference's default: 38 us per step, all of it launch cost), so
+// sphhip_step captures GRAPH_STEPS consecutive steps of the stream into a hipGraph once and replays it.
+// GRAPH_STEPS = 8 because the host-side state a step advances (ping-pong buffers, the two cell tables,
+// the ring of 8 particle-count words) is back where it started after 8 steps -- which is not assumed but
+// checked: the signature of that state before and after the capture must agree, else the capture is
+// dropped and the steps are enqueued one by one as before.  What a step decides from mapped host memory
+// (grid sizes, tile height, whether the dense follow-up kernels run) is frozen into the graph; all of
+// it only affects speed, never results, and the signature includes those decisions, so a scene that
+// changes regime gets a new capture at the next call.
+constexpr int GRAPH_STEPS = 8;
+constexpr int GRAPH_MAX_N = 1 << 17;
+
+static std::vector<uint64_t> step_sig(const SphCtx* c, float mx, float my, float strength) {
+    auto u = [](const void* p) { return (uint64_t)(uintptr_t)p; };
+    auto f = [](float x) { uint32_t b; memcpy(&b, &x, 4); return (uint64_t)b; };
+    const int dd = ((volatile int*)c->h_dense)[0], df = ((volatile int*)c->h_dense)[1];
+    return {u(c->pos), u(c->vel), u(c->pos2), u(c->vel2), u(c->rho), u(c->prs), u(c->rho2), u(c->prs2), u(c->idv), u(c->idv2),
+            u(c->keys), u(c->keys2), u(c->perm), u(c->perm2), u(c->cell_start), u(c->d_n), u(c->stream),
+            (uint64_t)c->cell_cur, (uint64_t)c->n_slot, (uint64_t)c->n, (uint64_t)c->tile_cells, (uint64_t)c->pair_cap,
+            (uint64_t)c->pair_threads, (uint64_t)c->grid_valid, (uint64_t)c->counts_valid, (uint64_t)c->slice_valid,
+            (uint64_t)c->tiles_valid, (uint64_t)c->cell_next_zeroed, (uint64_t)c->mask_tile_cells, (uint64_t)c->mask_cap,
+            (uint64_t)c->tab_clo, (uint64_t)c->tab_chi, (uint64_t)c->use_masks, (uint64_t)c->fast_div,
+            (uint64_t)(dd != 0), (uint64_t)(df != 0), f(mx), f(my), f(strength)};
+}
+
+static bool graph_possible(const SphCtx* c) {
+    return !c->graph_off && c->stream != nullptr && c->n_exact && c->n > 0 && c->n <= GRAPH_MAX_N && !c->profiling &&
+           c->grid_counting && !c->pending_drop && !c->tail_appended && c->col_lo == 0 && c->col_hi == c->dc.nx;
+}
+
+static void drop_step_graph(SphCtx* c) {
+    if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
+    c->step_graph = nullptr;
+    c->step_graph_sig.clear();
+}
+
+// Enqueues GRAPH_STEPS steps as one graph launch (after one plain step if a new capture is needed: it
+// leaves the host state in its steady after-a-step form).  advanced = steps enqueued; 0 (host state
+// untouched): the caller steps one by one.
+static int graph_steps(SphCtx* c, float mx, float my, float strength, int& advanced) {
+    advanced = 0;
+    sph_adapt_tile_cells(c, c->n);
+    std::vector<uint64_t> sig = step_sig(c, mx, my, strength);
+    if (!(c->step_graph && sig == c->step_graph_sig)) {
+        drop_step_graph(c);
+        int rc = step_once(c, mx, my, strength);
+        if (rc) return rc;
+        advanced = 1;
+        sph_adapt_tile_cells(c, c->n);
+        sig = step_sig(c, mx, my, strength);
+        const SphCtx saved = *c;
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+            (void)hipGetLastError();
+            c->graph_off = true;
+            return SPHHIP_OK;
+        }
+        for (int s = 0; s < GRAPH_STEPS && !rc; s++) rc = step_once(c, mx, my, strength);
+        const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        hipGraphExec_t exec = nullptr;
+        bool ok = !rc && e == hipSuccess && graph && step_sig(c, mx, my, strength) == sig;
+        if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {  // nothing of the capture was enqueued: back to the state before it, no more graphs
+            (void)hipGetLastError();
+            *c = saved;
+            c->graph_off = true;
+            return SPHHIP_OK;
+        }
+        c->step_graph = exec;
+        c->step_graph_sig = sig;
+    }
+    HIP_TRY(hipGraphLaunch(c->step_graph, c->stream));
+    advanced += GRAPH_STEPS;
+    return SPHHIP_OK;
+}
+
 extern "C" int sphhip_step(SphCtx* c, float mx, float my, float strength, int nsteps) {
     NEED_STATE(c);
     if (nsteps < 0) return fail(SPHHIP_EINVAL, "sphhip_step: nsteps < 0");
-    for (int s = 0; s < nsteps; s++) {
-        int rc = sph_grid_build(c, false);
-        if (rc) return rc;
-        rc = sph_density_launch(c);
-        if (rc) return rc;
-        rc = sph_force_launch(c, mx, my, strength, true);
+    int s = 0;
+    if (nsteps >= 2 * GRAPH_STEPS + 2 && graph_possible(c)) {
+        // the mapped counters must describe this scene: one plain step and a wait, once
+        if (((volatile int*)c->h_host_tiles)[0] < 0 || ((volatile int*)c->h_dense)[0] < 0 || ((volatile int*)c->h_dense)[1] < 0) {
+            int rc = step_once(c, mx, my, strength);
+            if (rc) return rc;
+            s++;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        while (nsteps - s >= GRAPH_STEPS + 1 && graph_possible(c)) {
+            int advanced = 0;
+            int rc = graph_steps(c, mx, my, strength, advanced);
+            if (rc) return rc;
+            s += advanced;
+            if (advanced < GRAPH_STEPS) break;
+        }
+    }
+    for (; s < nsteps; s++) {
+        int rc = step_once(c, mx, my, strength);
         if (rc) return rc;
     }
     return SPHHIP_OK;

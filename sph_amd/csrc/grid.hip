@@ -492,6 +492,120 @@ __global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ a, int len
 }
 
 // ---------------------------------------------------------------------------------------------
+// The whole grid build of a small scene in one workgroup.  Below a few thousand particles the five
+// kernels above are pure launch latency (~5 us each, dependent): here one workgroup of 1024 threads
+// counts into an LDS cell table, scans it, scatters (id, source slot) into LDS, ranks cell-mates by id
+// and writes the reordered state, the cell table, the tile list of the pair kernels and the zeros of the
+// idle table.  Same results as the kernels above (the (key, id) order is canonical); used when the
+// particles and the maintained cell range fit (SMALL_MAX_N, SMALL_MAX_CELLS) and no ghost drop is pending.
+// ---------------------------------------------------------------------------------------------
+constexpr int SMALL_THREADS = 1024;
+constexpr int SMALL_MAX_N = 4 * SMALL_THREADS;
+constexpr int SMALL_MAX_CELLS = 4 * SMALL_THREADS;  // entries of the maintained range incl. the closing one
+
+template <bool CARRY_DENSITY>
+__global__ __launch_bounds__(SMALL_THREADS) void k_grid_small(
+    DevConsts c, const int* __restrict__ d_n, const float2* __restrict__ pos, const float2* __restrict__ vel,
+    const float* __restrict__ rho, const float* __restrict__ prs, const uint32_t* __restrict__ idv,
+    float2* __restrict__ pos_o, float2* __restrict__ vel_o, float* __restrict__ rho_o, float* __restrict__ prs_o,
+    uint32_t* __restrict__ idv_o, uint32_t* __restrict__ skeys_o, int* __restrict__ cell_start, int r_first, int r_len,
+    int col_min, int col_max, int* __restrict__ tile_count, int* __restrict__ n_sorted, TileListArgs tl,
+    int* __restrict__ zero_buf, int zero_words, int* __restrict__ zero_buf2, int zero_words2, int* __restrict__ err) {
+    __shared__ int s_start[SMALL_MAX_CELLS + 1];  // counts, then exclusive starts; index = cell - r_first
+    __shared__ uint32_t s_id[SMALL_MAX_N];
+    __shared__ uint16_t s_src[SMALL_MAX_N], s_key[SMALL_MAX_N];
+    __shared__ int s_wtot[SMALL_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(*d_n, SMALL_MAX_N);
+    for (int k = tid; k <= SMALL_MAX_CELLS; k += SMALL_THREADS) s_start[k] = 0;
+    if (tid == 0) *tile_count = 0;
+    __syncthreads();
+    // keys + arrival index within the cell (k_cell_count)
+    uint32_t key[4];
+    int arrival[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int i = r * SMALL_THREADS + tid;
+        key[r] = 0xffffffffu;
+        arrival[r] = 0;
+        if (i < n) {
+            const float2 p = pos[i];
+            const int cx = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
+            const int cy = sph_cell_coord(p.y, c.ymin, c.inv_cell, c.ny);
+            if (cx < col_min || cx >= col_max) {
+                atomicOr(err, SPH_ERR_OUT_OF_SLAB);
+            } else {
+                key[r] = (uint32_t)(cx * c.ny + cy);
+                arrival[r] = atomicAdd(&s_start[(int)key[r] - r_first], 1);
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan: thread t owns entries 4t .. 4t+3 (k_scan_*)
+    int v[4], run = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        v[r] = run;
+        run += s_start[tid * 4 + r];
+    }
+    int incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    int off = incl - run;
+    for (int w = 0; w < wave; w++) off += s_wtot[w];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int idx = tid * 4 + r;
+        s_start[idx] = v[r] + off;
+        if (idx < r_len) cell_start[r_first + idx] = v[r] + off;
+        if (idx == r_len - 1) *n_sorted = v[r] + off;  // the closing entry: particles sorted
+    }
+    __syncthreads();
+    // scatter into LDS in arrival order (k_cell_scatter)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (key[r] != 0xffffffffu) {
+            const int i = r * SMALL_THREADS + tid;
+            const int k = (int)key[r] - r_first;
+            const int slot = s_start[k] + arrival[r];
+            s_id[slot] = idv[i] & SPH_ID_MASK;
+            s_src[slot] = (uint16_t)i;
+            s_key[slot] = (uint16_t)k;
+        }
+    }
+    __syncthreads();
+    // rank among the cell-mates by id, reorder (k_rank_reorder)
+    const int n_s = s_start[r_len - 1];
+    for (int s = tid; s < n_s; s += SMALL_THREADS) {
+        const int k = s_key[s];
+        const int a = s_start[k], b = s_start[k + 1];
+        const uint32_t my = s_id[s];
+        int rank = 0;
+        for (int t = a; t < b; t++) rank += (s_id[t] < my) ? 1 : 0;
+        const int dst = a + rank;
+        const int src = s_src[s];
+        pos_o[dst] = pos[src];
+        vel_o[dst] = vel[src];
+        if (CARRY_DENSITY) {
+            rho_o[dst] = rho[src];
+            prs_o[dst] = prs[src];
+        }
+        idv_o[dst] = idv[src];
+        skeys_o[dst] = (uint32_t)(k + r_first);
+    }
+    __syncthreads();  // the cell table is complete (and visible to this workgroup)
+    for (int i0 = 0; i0 < tl.nthreads; i0 += SMALL_THREADS)
+        sph_tile_list_thread(i0 + tid, cell_start, c.ny, tl.tile_cells, tl.tiles_per_col, tl.col0, tl.ncols, tl.list, tl.count);
+    for (int k = tid; k < zero_words; k += SMALL_THREADS) zero_buf[k] = 0;
+    for (int k = tid; k < zero_words2; k += SMALL_THREADS) zero_buf2[k] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 static inline int ilog2_ceil(unsigned v) {
     int b = 0;
     while ((1u << b) < v && b < 31) b++;
@@ -517,6 +631,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     const int r_len = (chi - clo) * c->dc.ny + 1;             // cells of the range + the closing entry
     const int r_parts = (r_len + SCAN_CHUNK - 1) / SCAN_CHUNK;
     bool range_moved = false;
+    bool fused = false;  // k_grid_small did the whole build
     if (c->grid_counting) {
         {
             PhaseScope ps(c, SPHHIP_PH_HASH);
@@ -533,14 +648,26 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             c->cell_cur = next;
             c->cell_start = c->cell_buf[next];
             c->cell_next_zeroed = false;
-            if (n > 0) {
+            fused = n > 0 && n <= SMALL_MAX_N && r_len <= SMALL_MAX_CELLS && !prev_table && !c->pending_drop && c->small_grid;
+            if (fused) {
+                TileListArgs tl = {};
+                int lo = 0, hi = 0;
+                sph_tile_list_args(c, tl, lo, hi);
+                int* zero_buf = c->cell_buf[1 - c->cell_cur];
+                auto kern = carry_density ? k_grid_small<true> : k_grid_small<false>;
+                hipLaunchKernelGGL(kern, dim3(1), dim3(SMALL_THREADS), 0, st, c->dc, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv,
+                                   c->pos2, c->vel2, c->rho2, c->prs2, c->idv2, c->keys, c->cell_start, r_first, r_len, clo, chi,
+                                   c->counters + SPH_TILE_COUNT_SLOT, c->counters + SPH_N_SORTED_SLOT, tl, zero_buf + r_first,
+                                   r_len, zero_buf + len, r_parts, c->d_err);
+                LAUNCH_CHECK();
+            } else if (n > 0) {
                 hipLaunchKernelGGL(k_cell_count, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, c->d_n, c->keys2,
                                    c->perm2, c->cell_start, prev_table, c->counters + SPH_N_SORTED_SLOT,
                                    c->slice_lo * c->dc.ny, c->slice_hi * c->dc.ny, clo, chi, c->d_err);
                 LAUNCH_CHECK();
             }
         }
-        {
+        if (!fused) {
             PhaseScope ps(c, SPHHIP_PH_CELLS);
             // (the chunk sums are a kernel of their own: accumulating them with atomics in k_cell_count puts
             // thousands of atomics on a few hundred addresses, 0.4 us each -- measured 0.1 ms)
@@ -551,7 +678,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
                                c->pending_drop ? sph_n_slot_next(c) : (int*)nullptr);
             LAUNCH_CHECK();
         }
-        if (n > 0) {
+        if (n > 0 && !fused) {
             PhaseScope ps(c, SPHHIP_PH_SORT);
             hipLaunchKernelGGL(k_cell_scatter, dim3((n + 255) / 256), dim3(256), 0, st, c->keys2, c->perm2, c->idv, c->d_n,
                                c->cell_start, c->keys, c->perm, c->ids_sorted);
@@ -621,7 +748,9 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             tail = (tl.nthreads + 255) / 256;
         }
         int* zero_buf = c->cell_buf[1 - c->cell_cur];
-        if (carry_density)
+        if (fused) {
+            // (k_grid_small has reordered, listed the tiles and zeroed the idle table)
+        } else if (carry_density)
             hipLaunchKernelGGL(k_rank_reorder<true>, dim3(nb + tail), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
                                c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
                                c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf + r_first, r_len, zero_buf + len, r_parts);

@@ -1414,7 +1414,9 @@ void sph_adapt_tile_cells(SphCtx* c, int n) {
     auto cand = [&](int tc) { return occ * 3.0 * (tc + 2); };
     int want = c->tile_cells;
     const bool starved = (long long)tiles * cells < (long long)8 * c->num_cus * c->tile_cells;  // < 8 tiles per CU
-    if (starved && cand(want) > 0.9 * c->pair_cap) {
+    if ((long long)tiles * cells <= 4ll * c->num_cus) {
+        want = 1;  // a tiny grid (the reference box has 169 cells): one cell per workgroup, the shortest critical path
+    } else if (starved && cand(want) > 0.9 * c->pair_cap) {
         while (want > 1 && cand(want) > 0.9 * c->pair_cap) want--;
     } else {
         while (want < c->tile_cells_max && cand(want + 1) < 0.6 * c->pair_cap) want++;

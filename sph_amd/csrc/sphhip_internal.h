@@ -79,6 +79,7 @@ struct SphCtx {
     uint32_t* nmask = nullptr;  // in-range bit masks of the last density pass: word w of slot s at [w * n_max + s]
     int mask_tile_cells = 0, mask_cap = 0;  // tiling the masks were built with
     bool grid_counting = true;  // counting sort by cell (SPHHIP_GRID=radix: the LSD radix sort)
+    bool small_grid = true;     // SPHHIP_SMALL_GRID=0: never the one-workgroup grid build (grid.hip: k_grid_small)
     bool lazy_pack = true;      // SPHHIP_LAZY_PACK=0: sphhip_pack_halo_async always compacts
     bool use_masks = true;      // SPHHIP_USE_MASKS=0: k_force always scans
 
@@ -106,6 +107,12 @@ struct SphCtx {
     int* h_dense = nullptr;                      // mapped host ints: entries of the last dense density / force kernel (-1: unknown)
     int* d_dense = nullptr;                      // their device address
     void* staging = nullptr;                     // AoS staging for upload / download (28 B * n_max)
+
+    // sphhip_step replays GRAPH_STEPS captured steps as one hipGraph when the scene is small enough to be
+    // launch-bound (ctx.hip)
+    hipGraphExec_t step_graph = nullptr;
+    std::vector<uint64_t> step_graph_sig;        // host state the graph was captured in (and returns to)
+    bool graph_off = false;                      // SPHHIP_GRAPH=0, or a capture failed
 
     bool profiling = false;
     unsigned profile_mask = ~0u;  // bit ph: bracket that phase with events

@@ -324,6 +324,33 @@ def test_dense_reference_box_bit_exact(n, cap, steps):
     assert orc.same_bits(got, want)
 
 
+def test_graph_replay_equals_plain_steps(monkeypatch):
+    """Small scenes replay 8 captured steps as one hipGraph (ctx.hip: graph_steps).  Same bits as the
+    plain launches (SPHHIP_GRAPH=0) and as the oracle -- across a change of the mouse arguments (new
+    capture), a new upload with another particle count, and step counts that are not multiples of 8."""
+    runs = {}
+    for env in ("0", "1"):
+        monkeypatch.setenv("SPHHIP_GRAPH", env)
+        got = []
+        with Solver(P, n_max=4096) as s:
+            s.upload(scenes.lattice(1024))
+            s.stepSimulation(nsteps=61)
+            got.append(s.download())
+            s.stepSimulation((1.0, 1.0), 50000.0, 45)
+            got.append(s.download())
+            s.upload(scenes.lattice(2704))
+            s.stepSimulation(nsteps=40)
+            s.stepSimulation(nsteps=3)
+            got.append(s.download())
+        runs[env] = got
+    for x, y in zip(runs["0"], runs["1"]):
+        assert orc.same_bits(x, y)
+    want = O.step_cells(P, scenes.lattice(1024), 61)
+    assert orc.same_bits(runs["1"][0], want)
+    want = O.step_cells(P, want, 45, mouse=(1.0, 1.0), strength=50000.0)
+    assert orc.same_bits(runs["1"][1], want)
+
+
 def test_full_size_dam_break_bit_exact():
     """BASELINE configs[1] at full size (1M-particle dam break): the cell-list oracle finishes a step in a
     fraction of a second, so the whole state is compared bit for bit after 3 steps, the neighbour counts
