@@ -698,10 +698,6 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
     uint32_t m = 0, m_next = 0;
     if (nw > 0) m = s_mask[tid];
     if (nw > 1) m_next = s_mask[THREADS + tid];
-#if defined(FORCE_EXPERIMENT) && FORCE_EXPERIMENT == 2
-    nw = 0;
-    m = 0;  // ablation: no pair loop
-#endif
     // pops the next U set bits of the lane and starts the LDS reads of those records
     auto fetch = [&](PairGroup& g) {
 #pragma unroll
@@ -729,11 +725,7 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
             ry[u] = pi.y - g.pq[u].y;
             r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
         }
-#if defined(FORCE_EXPERIMENT) && FORCE_EXPERIMENT == 1
-        for (int u = 0; u < U; u++) { tx[u] = rx[u] * g.aux[u].x + yd[u]; ty[u] = ry[u] * g.aux[u].w + r2[u]; }
-#else
         force_terms<U, true>(c, rx, ry, r2, pres_i, vi.x, vi.y, g.aux, yd, tx, ty);
-#endif
 #pragma unroll
         for (int u = 0; u < U; u++) {  // same order as the sequential sum
             fx += tx[u];

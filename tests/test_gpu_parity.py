@@ -373,6 +373,35 @@ def test_full_size_dam_break_bit_exact():
     assert got["pos"][:, 1].min() >= params.ymin and got["pos"][:, 1].max() <= params.ymax
 
 
+def test_full_size_uniform_box_bit_exact():
+    """BASELINE configs[2] at full size (4M-particle box filled wall to wall, ~50 neighbours): neighbour
+    counts and the whole state after 2 steps, bit for bit against the cell-list oracle."""
+    params, a = scenes.uniform_box(2048)
+    assert len(a) == 1 << 22
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.computeDensityPressure()
+        _, want_counts = O.density_cells(params, a.copy())
+        assert np.array_equal(s.neighbor_counts(), want_counts)
+        assert 45 < want_counts.mean() < 52
+        s.upload(a)
+        s.stepSimulation(nsteps=2)
+        got, ids = s.download(with_ids=True)
+    assert np.array_equal(np.sort(ids), np.arange(len(a)))
+    assert orc.same_bits(got, O.step_cells(params, a.copy(), 2))
+
+
+def test_full_size_16m_dam_break_one_step():
+    """The scene of BASELINE configs[3] (16M-particle dam break) on one GPU: one step, bit for bit."""
+    params, a = scenes.dam_break(4096)
+    assert len(a) == 1 << 24
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.stepSimulation(nsteps=1)
+        got = s.download()
+    assert orc.same_bits(got, O.step_cells(params, a, 1))
+
+
 def test_long_horizon_dam_break_bit_exact():
     """800 steps of a 16k-particle dam break: the column collapses, particles reach MAX_VEL, cells fill up to
     twice their initial population (tiles split, second batches of own particles), the grid is re-sorted 800
