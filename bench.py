@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = the workload per GPU (default, the driver's contract); strong = the named workload "
+                    "split over the GPUs (BASELINE configs[3]: --workload dam16m --scaling strong)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,8 +144,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-        # weak scaling: the fluid column gets `world` times wider, per-GPU particle count fixed
-        params, n_total, hist_fn, make_local = scenes.dam_break_sharded(cols * world, rows)
+        # weak scaling: the fluid column gets `world` times wider, per-GPU particle count fixed;
+        # strong scaling: the named scene as it is, split into `world` slabs
+        total_cols = cols * world if args.scaling == "weak" else cols
+        params, n_total, hist_fn, make_local = scenes.dam_break_sharded(total_cols, rows)
         drv = _lib.derive(params)
         solver = make_hip_slab(params, make_local, local_rank, hist=hist_fn(drv))
         step = lambda k: solver.step(nsteps=k)  # noqa: E731
@@ -234,13 +239,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": "2D dam-break, %d particles (%d x %d lattice at spacing H/4, box %.1f x %.1f, sph.h constants), fp32"
-                % (n_total, cols * world, rows, params.xmax - params.xmin, params.ymax - params.ymin),
+                % (n_total, n_total // rows, rows, params.xmax - params.xmin, params.ymax - params.ymin),
                 "name": name,
                 "particles": n_total,
                 "grid": [drv.nx, drv.ny],
