@@ -200,6 +200,7 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     if (const char* e = getenv("SPHHIP_USE_MASKS")) c->use_masks = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_GRAPH")) c->graph_off = atoi(e) == 0;
     if (const char* e = getenv("SPHHIP_SMALL_GRID")) c->small_grid = atoi(e) != 0;
+    if (const char* e = getenv("SPHHIP_DENSE_TP")) c->dense_tp = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_LAZY_PACK")) c->lazy_pack = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_GRID")) c->grid_counting = std::string(e) != "radix";
     if (const char* e = getenv("SPHHIP_PAIR_THREADS")) {
@@ -507,8 +508,16 @@ static std::vector<uint64_t> step_sig(const SphCtx* c, float mx, float my, float
 }
 
 static bool graph_possible(const SphCtx* c) {
-    return !c->graph_off && c->stream != nullptr && c->n_exact && c->n > 0 && c->n <= GRAPH_MAX_N && !c->profiling &&
-           c->grid_counting && !c->pending_drop && !c->tail_appended && c->col_lo == 0 && c->col_hi == c->dc.nx;
+    if (c->graph_off || c->stream == nullptr || !c->n_exact || c->n <= 0 || c->n > GRAPH_MAX_N || c->profiling ||
+        !c->grid_counting || c->pending_drop || c->tail_appended || c->col_lo != 0 || c->col_hi != c->dc.nx)
+        return false;
+    // (a caller that is itself capturing this stream gets the plain launches recorded into its graph)
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st == hipStreamCaptureStatusNone;
 }
 
 static void drop_step_graph(SphCtx* c) {

@@ -247,6 +247,7 @@ __device__ __forceinline__ void for_each_tile(const TileQueue& q, Body&& body) {
 // (slow, correct) and raises the mapped flag, so that a later launch defers again.
 // ---------------------------------------------------------------------------------------------
 constexpr int DENSE_THREADS = 256;
+constexpr int DENSE_U = 8, DENSE_Q = 24;  // pairs in flight / queued per round in k_force_dense (rows <= 8 KB / DENSE_THREADS)
 
 struct DenseSink {
     int4* list;      // (col, first row, rows, part)
@@ -255,6 +256,7 @@ struct DenseSink {
     int* host_flag;  // mapped host memory
     int* err;
     int defer;
+    int part;        // own particles per entry
 };
 
 // true: the sub-tile went to the list (uniform over the workgroup).
@@ -263,7 +265,7 @@ __device__ __forceinline__ bool dense_defer(const DenseSink& d, const TileGeom& 
         if (!d.defer) {
             *(volatile int*)d.host_flag = 1;
         } else {
-            const int nparts = (g.own_hi - g.own_lo + DENSE_THREADS - 1) / DENSE_THREADS;
+            const int nparts = (g.own_hi - g.own_lo + d.part - 1) / d.part;
             const int e = atomicAdd(d.count, nparts);
             if (e + nparts <= d.capacity) {
                 for (int p = 0; p < nparts; p++) d.list[e + p] = make_int4(g.col, g.cy0, g.cy1 - g.cy0, p);
@@ -572,7 +574,7 @@ __device__ __forceinline__ void integrate_one(const DevConsts& c, float2& p, flo
 // ---------------------------------------------------------------------------------------------
 // Heavy phase of one round: evaluates the qn queued pairs of every lane (byte offsets from `lo` in
 // s_q), FORCE_HEAVY_UNROLL at a time, in queue order.
-template <int THREADS, bool FAST, bool WIN>
+template <int THREADS, bool FAST, bool WIN, int U = FORCE_HEAVY_UNROLL>
 __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s_rec,
                                             uint8_t* s_q, int qn, int lo, int self_off, float2 pi, float2 vi,
                                             float pres_i, float& fx, float& fy, int tix) {
@@ -581,16 +583,16 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
     // +0 term to pad with: exhausted slots evaluate the window's first record and are left out of the sum.
     if (!WIN) {
 #pragma unroll
-        for (int u = 0; u < FORCE_HEAVY_UNROLL - 1; u++) s_q[(qn + u) * THREADS + tid] = (uint8_t)self_off;
+        for (int u = 0; u < U - 1; u++) s_q[(qn + u) * THREADS + tid] = (uint8_t)self_off;
     }
-    for (int t = 0; __any(t < qn); t += FORCE_HEAVY_UNROLL) {
-        int jj[FORCE_HEAVY_UNROLL];
-        float tx[FORCE_HEAVY_UNROLL], ty[FORCE_HEAVY_UNROLL];
-        float rx[FORCE_HEAVY_UNROLL], ry[FORCE_HEAVY_UNROLL], r2[FORCE_HEAVY_UNROLL];
-        float4 aj[FORCE_HEAVY_UNROLL];
-        float yd[FORCE_HEAVY_UNROLL];
+    for (int t = 0; __any(t < qn); t += U) {
+        int jj[U];
+        float tx[U], ty[U];
+        float rx[U], ry[U], r2[U];
+        float4 aj[U];
+        float yd[U];
 #pragma unroll
-        for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+        for (int u = 0; u < U; u++) {
             int e = s_q[(t + u) * THREADS + tid];
             if (WIN)
                 jj[u] = lo + ((t + u < qn) ? e : 0);
@@ -598,7 +600,7 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
                 jj[u] = lo + ((t < qn) ? e : self_off);  // a lane whose queue is exhausted re-evaluates itself
         }
 #pragma unroll
-        for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+        for (int u = 0; u < U; u++) {
             const float4* rec = reinterpret_cast<const float4*>(s_rec + jj[u]);
             aj[u] = rec[0];
             const float4 q = rec[1];  // pos.x, pos.y, yd
@@ -607,10 +609,10 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
             ry[u] = pi.y - q.y;
             r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
         }
-        force_terms<FORCE_HEAVY_UNROLL, FAST>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, yd, tx, ty);
+        force_terms<U, FAST>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, yd, tx, ty);
         // same order as the sequential sum: force += term(t); force += term(t+1); ...
 #pragma unroll
-        for (int u = 0; u < FORCE_HEAVY_UNROLL; u++) {
+        for (int u = 0; u < U; u++) {
             if (FAST && !WIN) {
                 fx += tx[u];
                 fy += ty[u];
@@ -634,7 +636,9 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
 // +0, the pressure factor is finite because rho_i is in the safe range) and force + 0 == force --
 // and the queue tail is padded with the particle itself, so the accumulation needs no predicate.
 // !FAST keeps the reference's `j == i` test (sph.cpp:63) and a predicated accumulation.
-template <int THREADS, bool FAST, bool WIN = false>
+// (U pairs in flight per lane, Q queued per round: the tuned kernels run many waves per SIMD and do best with
+// 2 and 8; the dense kernel runs one wave per SIMD and wants the instruction-level parallelism of 8 and 24)
+template <int THREADS, bool FAST, bool WIN = false, int U = FORCE_HEAVY_UNROLL, int Q = FORCE_Q>
 __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* s_rec,
                                              uint8_t* s_q, int j, int hi, int self, float2 pi, float2 vi,
                                              float pres_i, float& fx, float& fy, int tix) {
@@ -644,8 +648,8 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* 
     const int self_off = self - lo;
     while (__any(j < hi)) {
         int qn = 0;
-        while (__any((j < hi) && (qn < FORCE_Q))) {
-            if ((j < hi) && (qn < FORCE_Q)) {
+        while (__any((j < hi) && (qn < Q))) {
+            if ((j < hi) && (qn < Q)) {
                 float2 q[FORCE_SCAN_UNROLL];
 #pragma unroll
                 for (int u = 0; u < FORCE_SCAN_UNROLL; u++) q[u] = s_rec[j + u].pos;  // may run into the row sentinels
@@ -663,7 +667,7 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* 
                 j += FORCE_SCAN_UNROLL;
             }
         }
-        force_heavy<THREADS, FAST, WIN>(c, s_rec, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy, tix);
+        force_heavy<THREADS, FAST, WIN, U>(c, s_rec, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy, tix);
     }
 }
 
@@ -1149,16 +1153,143 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_force_dense(
             for (int w0 = k0; __any(w0 < k1); w0 += FORCE_MAX_RANGE) {
                 const int w1 = min(w0 + FORCE_MAX_RANGE, k1);
                 if (fast)
-                    force_rounds<THREADS, true, true>(c, s_rec, s_q, w0 - base, w1 - base, self_seq - base, pi, vi, pres_i,
-                                                      fx, fy, tix);
+                    force_rounds<THREADS, true, true, DENSE_U, DENSE_Q>(c, s_rec, s_q, w0 - base, w1 - base, self_seq - base, pi, vi,
+                                                                        pres_i, fx, fy, tix);
                 else
-                    force_rounds<THREADS, false, true>(c, s_rec, s_q, w0 - base, w1 - base, self_seq - base, pi, vi, pres_i,
-                                                       fx, fy, tix);
+                    force_rounds<THREADS, false, true, DENSE_U, DENSE_Q>(c, s_rec, s_q, w0 - base, w1 - base, self_seq - base, pi, vi,
+                                                                         pres_i, fx, fy, tix);
             }
         }
         if (have) {
             if (valid) {
                 force_epilogue<FUSE>(c, fx, fy, pi, vi, dens_i, mx, my, strength);
+                if (FUSE) integrate_one(c, pi, vi);
+            }
+            if (FUSE) pos_o[s] = pi;  // sph.cpp:59,103: invalid particles are left alone
+            vel_o[s] = vi;
+        }
+    });
+}
+
+// Term-parallel variant for scenes whose dense sub-tiles are too few to fill the GPU with one lane per
+// particle (the reference box: 16 k particles are 256 waves, each walking ~900 candidates alone on its
+// SIMD): here a wave takes ONE own particle at a time and its 64 lanes evaluate 64 consecutive candidates
+// of the chunk; the in-range terms are then added in lane order (ascending candidate = the canonical
+// order; `x + (+0)` for the others is exact, the sum never is -0).  Same terms, same order, same bits --
+// about 3x the instructions per pair of the lane-per-particle kernel, but 64x its parallelism.  Entries
+// are DENSE_PART_TP own particles; their partial sums live in LDS between the chunks.  Measured on the
+// reference box (force pass per step, this kernel / k_force_dense): N=8192 0.10 / 0.17 ms, N=16384
+// 0.16 / 0.25 ms, N=65536 1.58 / 1.32 ms -- the host picks it below ~40 k dense particles.
+constexpr int DENSE_PART_TP = 16;
+
+template <bool FUSE>
+__global__ __launch_bounds__(DENSE_THREADS) void k_force_dense_tp(
+    DevConsts c, const float2* __restrict__ pos, const float2* __restrict__ vel, const float* __restrict__ rho,
+    const float* __restrict__ prs, const uint32_t* __restrict__ idv, const uint32_t* __restrict__ skeys,
+    const int* __restrict__ cell_start, float2* __restrict__ pos_o, float2* __restrict__ vel_o, DenseQueue q, int cap,
+    float mx, float my, float strength, int allow_fast) {
+    constexpr int THREADS = DENSE_THREADS;
+    extern __shared__ __align__(16) float4 s_dyn[];
+    PairRec* s_rec = reinterpret_cast<PairRec*>(s_dyn);
+    int* s_off = reinterpret_cast<int*>(s_rec + cap);
+    int* s_gs = s_off + PAIR_MAXC + 1;
+    int* s_wave = s_gs + PAIR_MAXC;
+    float2* s_f = reinterpret_cast<float2*>(s_wave + 8);  // (the queue region of the other force kernels)
+    for_each_dense(q, [&](int4 ent, int tix) {
+        TileGeom g;
+        tile_setup<THREADS>(c, cell_start, ent.x, ent.y, ent.y + ent.z, g, s_off, s_gs, s_wave, tix);
+        const int lane = tix & 63, wave = tix >> 6;
+        const int own0 = g.own_lo + ent.w * DENSE_PART_TP;
+        const int n_own = min(DENSE_PART_TP, g.own_hi - own0);
+        int unsafe = allow_fast ? 0 : 1;
+        if (tix < n_own) {
+            s_f[tix] = make_float2(0.0f, 0.0f);
+            const float di = rho[own0 + tix], pi_ = prs[own0 + tix];
+            unsafe |= (di == 0.0f || !sph_safe_operand(di) || !sph_safe_operand(pi_)) ? 1 : 0;
+        }
+        __syncthreads();
+        const float inf = __builtin_inff();
+        for (int base = 0; base < g.total; base += cap) {
+            if (base) __syncthreads();  // the previous chunk has been read
+            dense_stage_chunk<THREADS>(
+                g, s_off, base, cap, tix,
+                [&](int dst, int cc, int k) {
+                    const int j = s_gs[cc] + k;
+                    float2 qj = pos[j];
+                    const float2 w = vel[j];
+                    const float dj = rho[j], pj = prs[j];
+                    unsafe |= (dj == 0.0f || !sph_safe_operand(dj) || !sph_safe_operand(pj)) ? 1 : 0;
+                    if (idv[j] & SPH_INVALID_BIT) qj = make_float2(inf, inf);  // sph.cpp:63
+                    PairRec rec;
+                    rec.aux = make_float4(w.x, w.y, dj, pj);
+                    rec.pos = qj;
+                    rec.yd = sph_rcp_refined(dj);
+                    rec.pad = 0.0f;
+                    s_rec[dst] = rec;
+                },
+                [&](int dst) {
+                    PairRec rec;
+                    rec.aux = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+                    rec.pos = make_float2(inf, inf);
+                    rec.yd = 1.0f;
+                    rec.pad = 0.0f;
+                    s_rec[dst] = rec;
+                });
+            const bool fast = !__syncthreads_or(unsafe);
+            for (int o = wave; o < n_own; o += THREADS / 64) {  // (everything about particle o is wave-uniform)
+                const int s = own0 + o;
+                if (idv[s] & SPH_INVALID_BIT) continue;  // sph.cpp:59
+                const float2 pi = pos[s], vi = vel[s];
+                const float pres_i = prs[s];
+                const int cy = (int)skeys[s] - g.col * c.ny;
+                const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
+                const int self_cell = 3 * (cy - g.ylo) + 1;
+                const int self_seq = s_off[self_cell] + (s - s_gs[self_cell]);
+                const int k0 = max(s_off[3 * r0], base), k1 = min(s_off[3 * r1 + 3] - PAIR_ROW_PAD, base + cap);
+                float2 f = s_f[o];
+                for (int kk = k0; kk < k1; kk += 64) {
+                    const int k = kk + lane;
+                    float tx = 0.0f, ty = 0.0f;
+                    bool in = false;
+                    if (k < k1 && k != self_seq) {  // sph.cpp:63
+                        const float4* rec = reinterpret_cast<const float4*>(s_rec + (k - base));
+                        const float4 qv = rec[1];
+                        const float rx = pi.x - qv.x, ry = pi.y - qv.y;
+                        const float r2 = rx * rx + ry * ry;
+                        if (!(r2 >= c.h2)) {  // sph.cpp:66
+                            in = true;
+                            if (fast) {
+                                const float rxa[1] = {rx}, rya[1] = {ry}, r2a[1] = {r2}, yda[1] = {qv.z};
+                                const float4 aja[1] = {rec[0]};
+                                float txa[1], tya[1];
+                                force_terms<1, true>(c, rxa, rya, r2a, pres_i, vi.x, vi.y, aja, yda, txa, tya);
+                                tx = txa[0];
+                                ty = tya[0];
+                            } else {
+                                force_term(c, rx, ry, r2, pres_i, vi.x, vi.y, rec[0], tx, ty);
+                            }
+                        }
+                    }
+                    unsigned long long bal = __ballot(in);
+                    while (bal) {  // ascending candidate; v_readlane (the lane index is wave-uniform), not an LDS permute
+                        const int b = __ffsll((long long)bal) - 1;
+                        bal &= bal - 1;
+                        f.x += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tx), b));
+                        f.y += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty), b));
+                    }
+                }
+                if (lane == 0) s_f[o] = f;
+            }
+        }
+        __syncthreads();
+        if (tix < n_own) {
+            const int s = own0 + tix;
+            OwnParticle own;
+            own.load(s, true, pos, vel, rho, prs, idv, skeys);
+            float2 pi = own.p, vi = own.v;
+            if (!(own.idv & SPH_INVALID_BIT)) {
+                float2 f = s_f[tix];
+                force_epilogue<FUSE>(c, f.x, f.y, pi, vi, own.d, mx, my, strength);
                 if (FUSE) integrate_one(c, pi, vi);
             }
             if (FUSE) pos_o[s] = pi;  // sph.cpp:59,103: invalid particles are left alone
@@ -1423,7 +1554,7 @@ void sph_adapt_tile_cells(SphCtx* c, int n) {
 // Sink / queue of the dense sub-tiles for one pair-kernel launch (which: 0 density, 1 force) and the
 // decision whether the follow-up kernel runs: yes unless the last one reported an empty list (the
 // mapped ints start at -1 = unknown).
-static int dense_prepare(SphCtx* c, int which, DenseSink& sink, DenseQueue& dq, int& grid) {
+static int dense_prepare(SphCtx* c, int which, DenseSink& sink, DenseQueue& dq, int& grid, bool& term_parallel) {
     const int seen = ((volatile int*)c->h_dense)[which];
     int* count = c->counters + SPH_DENSE_COUNT_SLOT;
     sink.list = c->dense_list;
@@ -1432,6 +1563,10 @@ static int dense_prepare(SphCtx* c, int which, DenseSink& sink, DenseQueue& dq, 
     sink.host_flag = c->d_dense + which;
     sink.err = c->d_err;
     sink.defer = seen != 0 ? 1 : 0;
+    // force pass: the term-parallel kernel while the dense particles (going by the last list) would not fill
+    // the GPU with a lane each
+    term_parallel = which == 1 && c->dense_tp && (seen < 0 || (long long)seen * c->dense_force_part < 40ll * 1024);
+    sink.part = term_parallel ? DENSE_PART_TP : DENSE_THREADS;
     dq.list = c->dense_list;
     dq.count = count;
     dq.capacity = c->dense_cap;
@@ -1439,7 +1574,11 @@ static int dense_prepare(SphCtx* c, int which, DenseSink& sink, DenseQueue& dq, 
     grid = 0;
     if (sink.defer) {
         HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), c->stream));
-        const long long want = seen > 0 ? (long long)seen + seen / 8 + 8 : 0;
+        long long want = seen > 0 ? (long long)seen + seen / 8 + 8 : 0;
+        if (which == 1) {
+            want = want * c->dense_force_part / sink.part;  // (the last count was in entries of the last part size)
+            c->dense_force_part = sink.part;
+        }
         grid = (int)std::min<long long>(std::max<long long>(want, 2 * c->num_cus), 1 << 20);
     }
     return SPHHIP_OK;
@@ -1462,7 +1601,8 @@ int sph_density_launch(SphCtx* c) {
     DenseSink sink;
     DenseQueue dq;
     int dense_grid = 0;
-    if ((rc = dense_prepare(c, 0, sink, dq, dense_grid))) return rc;
+    bool tp = false;
+    if ((rc = dense_prepare(c, 0, sink, dq, dense_grid, tp))) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, c->pos, c->keys, c->cell_start, c->rho,
                        c->prs, c->ncount, c->nmask, c->n_max, q, lo, hi, c->tile_cells, c->pair_cap, sink);
     LAUNCH_CHECK();
@@ -1499,14 +1639,16 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     DenseSink sink;
     DenseQueue dq;
     int dense_grid = 0;
-    if ((rc = dense_prepare(c, 1, sink, dq, dense_grid))) return rc;
+    bool tp = false;
+    if ((rc = dense_prepare(c, 1, sink, dq, dense_grid, tp))) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv,
                        c->keys, c->cell_start, c->pos2, c->vel2, q, flo, fhi, c->tile_cells, c->pair_cap, c->col_lo,
                        c->col_hi, mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr,
                        c->n_max, sink);
     LAUNCH_CHECK();
     if (sink.defer) {
-        auto dkern = fuse_integrate ? k_force_dense<true> : k_force_dense<false>;
+        auto dkern = tp ? (fuse_integrate ? k_force_dense_tp<true> : k_force_dense_tp<false>)
+                        : (fuse_integrate ? k_force_dense<true> : k_force_dense<false>);
         hipLaunchKernelGGL(dkern, dim3(dense_grid), dim3(DENSE_THREADS), pair_lds_bytes(c->pair_cap, true, DENSE_THREADS),
                            c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv, c->keys, c->cell_start, c->pos2, c->vel2,
                            dq, c->pair_cap, mx, my, strength, c->fast_div ? 1 : 0);

@@ -106,6 +106,8 @@ struct SphCtx {
     int dense_cap = 0;                           // its capacity in entries
     int* h_dense = nullptr;                      // mapped host ints: entries of the last dense density / force kernel (-1: unknown)
     int* d_dense = nullptr;                      // their device address
+    int dense_force_part = 256;                  // own particles per entry of the last force-pass list
+    bool dense_tp = true;                        // SPHHIP_DENSE_TP=0: never the term-parallel dense force kernel
     void* staging = nullptr;                     // AoS staging for upload / download (28 B * n_max)
 
     // sphhip_step replays GRAPH_STEPS captured steps as one hipGraph when the scene is small enough to be

@@ -302,12 +302,15 @@ def test_scaled_scene_miniatures():
         assert np.abs(got["pos"] - ref["pos"]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("tp", ["1", "0"])
 @pytest.mark.parametrize("n,cap,steps", [(8192, 0, 4), (8192, 200, 3), (16384, 0, 3), (16384, 448, 2)])
-def test_dense_reference_box_bit_exact(n, cap, steps):
+def test_dense_reference_box_bit_exact(monkeypatch, n, cap, steps, tp):
     """The reference's own scene at a large N (main.cpp's fixed 1.9 x 1.9 box: 50-100 particles per cell,
     stencil ranges of 400-900 candidates): windows of long ranges, candidate sequences staged chunk by
     chunk, and the tile height the host adapts after the first step must all keep every bit.  Neighbour
-    counts against the all-pairs predicate of the reference."""
+    counts against the all-pairs predicate of the reference.  tp: the term-parallel dense force kernel
+    (a wave per particle, ordered sum over the lanes) or the lane-per-particle one."""
+    monkeypatch.setenv("SPHHIP_DENSE_TP", tp)
     a = scenes.lattice(n)
     with Solver(P, n_max=n) as s:
         if cap:
