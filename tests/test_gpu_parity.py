@@ -354,6 +354,42 @@ def test_graph_replay_equals_plain_steps(monkeypatch):
     assert orc.same_bits(runs["1"][1], want)
 
 
+@pytest.mark.parametrize("seed", range(30))
+def test_random_scenes_fuzz(seed):
+    """Random scenes against the oracle, bit for bit: random particle counts, clustered positions (dense
+    cells, long stencil ranges: the dense kernels and their chunking), particles outside the walls (clamped
+    cell coordinates), random velocities, a few invalid particles, optional mouse force, random LDS budget."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 63, 64, 65, 300, 1000, 2500, 5000, 9000]))
+    if seed in (20, 25):
+        n = 50000  # enough dense particles for the lane-per-particle dense force kernel
+    a = np.zeros(n, scenes.PARTICLE_DTYPE)
+    centres = rng.uniform(0.1, 1.9, size=(int(rng.integers(1, 6)), 2))
+    spread = float(rng.choice([0.002, 0.02, 0.1, 0.5])) if n < 50000 else 0.15
+    pos = centres[rng.integers(0, len(centres), n)] + rng.normal(0.0, spread, size=(n, 2))
+    if seed % 3 == 0:
+        pos[rng.integers(0, n, max(1, n // 50))] += rng.uniform(-3.0, 3.0, size=(max(1, n // 50), 2))  # outside the walls
+    a["pos"] = pos.astype(np.float32)
+    a["vel"] = rng.normal(0.0, 1.0, size=(n, 2)).astype(np.float32)
+    a["density"] = 1000.0
+    a["valid"] = 1
+    if seed % 4 == 1:
+        a["valid"][rng.integers(0, n, max(1, n // 20))] = 0
+    mouse, strength = ((1.0, 1.0), 50000.0) if seed % 2 else ((0.0, 0.0), 0.0)
+    steps = 3
+    want = O.step_cells(P, a.copy(), steps, mouse=mouse, strength=strength)
+    with Solver(P, n_max=n) as s:
+        cap = int(rng.choice([0, 0, 64, 150, 448]))
+        if cap:
+            s.set_tuning(0, cap)
+        s.upload(a)
+        for _ in range(steps):
+            s.stepSimulation(mouse, strength, 1)
+            s.synchronize()
+        got = s.download()
+    assert orc.same_bits_nan(got, want)
+
+
 def test_full_size_dam_break_bit_exact():
     """BASELINE configs[1] at full size (1M-particle dam break): the cell-list oracle finishes a step in a
     fraction of a second, so the whole state is compared bit for bit after 3 steps, the neighbour counts
