@@ -25,7 +25,13 @@ def _free_port():
     return p
 
 
-def _scene():
+def _scene(kind="dam"):
+    if kind == "dense":  # the reference box at 48 particles per cell: dense sub-tiles on both sides of the boundary
+        from sph_amd.params import SphParams
+
+        a = scenes.lattice(8192)
+        a["vel"][:, 0] = np.where(a["pos"][:, 1] > 1.0, 3.0, -3.0).astype(np.float32)
+        return SphParams.reference(), a
     p, a = scenes.dam_break(96, 64)
     a["vel"][:, 0] = 4.0
     a["pos"][:, 0] += np.float32(3.0)
@@ -33,14 +39,14 @@ def _scene():
     return p, a
 
 
-def _worker(rank, world, port, nsteps, out_path):
+def _worker(rank, world, port, nsteps, out_path, kind="dam"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     from sph_amd.slab import make_hip_slab
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        params, a = _scene()
+        params, a = _scene(kind)
         slab = make_hip_slab(params, a, device=0)
         n0 = slab.local_count()
         slab.step(nsteps // 2)
@@ -68,3 +74,22 @@ def test_hip_slabs_equal_single_gpu(tmp_path, world, nsteps):
         single = s.download()
     assert orc.same_bits(got, single)
     assert orc.same_bits(got, orc.Oracle().step_cells(params, a.copy(), nsteps))
+
+
+def test_hip_slabs_dense_scene(tmp_path):
+    """Two slabs of the reference box at N=8192 (dense sub-tiles, adapted tile height, ghost columns that
+    are dense themselves), particles streaming across the boundary in both directions."""
+    from sph_amd.solver import Solver
+
+    out = str(tmp_path / "got.npy")
+    nsteps = 24
+    mp.spawn(_worker, args=(2, _free_port(), nsteps, out, "dense"), nprocs=2, join=True)
+    got = np.load(out)
+    params, a = _scene("dense")
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.stepSimulation(nsteps=nsteps)
+        single = s.download()
+    assert orc.same_bits(got, single)
+    assert orc.same_bits(got, orc.Oracle().step_cells(params, a.copy(), nsteps))
+
