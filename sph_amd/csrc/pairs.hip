@@ -247,7 +247,11 @@ __device__ __forceinline__ void for_each_tile(const TileQueue& q, Body&& body) {
 // (slow, correct) and raises the mapped flag, so that a later launch defers again.
 // ---------------------------------------------------------------------------------------------
 constexpr int DENSE_THREADS = 256;
-constexpr int DENSE_U = 8, DENSE_Q = 24;  // pairs in flight / queued per round in k_force_dense (rows <= 8 KB / DENSE_THREADS)
+constexpr int DENSE_U = 8, DENSE_Q = 24;  // pairs in flight / queued per round in k_force_dense
+// its byte queue (rows of one byte per thread) lives in the mask region of the force kernels' LDS layout: a
+// scan trip pushes at most FORCE_SCAN_UNROLL entries past DENSE_Q - 1, the evaluation reads whole groups of DENSE_U
+static_assert((DENSE_Q - 1 + FORCE_SCAN_UNROLL + DENSE_U - 1) / DENSE_U * DENSE_U <= (int)sizeof(uint32_t) * PAIR_MASK_WORDS,
+              "k_force_dense: queue rows exceed the LDS region");
 
 struct DenseSink {
     int4* list;      // (col, first row, rows, part)
