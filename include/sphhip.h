@@ -149,6 +149,15 @@ int sphhip_integrate(SphCtx* ctx);
  * grid, density, then forces + velocity update + integrate + wall clamp fused in one kernel.
  * Replaces the 3-kernel loop of CUDA_performance_test (SPH/sph.cu:254-258). */
 int sphhip_step(SphCtx* ctx, float mouse_x, float mouse_y, float strength, int nsteps);
+/* One step in two halves, for a slab driver that overlaps the halo exchange with the step (replaces the
+ * Allgather-then-compute order of mpi_computeStep, SPH/MPI_sph.cpp:135-243, where every rank waits for the
+ * full state before it computes).  sphhip_step_begin: grid, density, and the force + integrate pass of the
+ * ghost columns and of the first edge_left / last edge_right owned columns -- everything the next halo
+ * messages are packed from.  sphhip_step_finish: the same pass over the remaining owned columns.  Between
+ * the two only sphhip_pack_halo_async (and stream / error queries) may be called; begin + finish give exactly
+ * the state of sphhip_step(..., 1). */
+int sphhip_step_begin(SphCtx* ctx, float mouse_x, float mouse_y, float strength, int edge_left, int edge_right);
+int sphhip_step_finish(SphCtx* ctx);
 
 /* ---- cell-list and neighbour diagnostics (parity: bit-exact integers) ------------------- */
 

@@ -433,6 +433,15 @@ extern "C" int sphhip_count(SphCtx* c, int* n) {
     do {                                                                         \
         if (!(c)) return fail(SPHHIP_EINVAL, "null context");                    \
         if (!(c)->have_state) return fail(SPHHIP_ESTATE, "no particles uploaded"); \
+        if ((c)->split.pending) return fail(SPHHIP_ESTATE, "sphhip_step_begin without sphhip_step_finish"); \
+        HIP_TRY(hipSetDevice((c)->device));                                      \
+    } while (0)
+
+// ... for the calls allowed between sphhip_step_begin and sphhip_step_finish
+#define NEED_STATE_MIDSTEP(c)                                                    \
+    do {                                                                         \
+        if (!(c)) return fail(SPHHIP_EINVAL, "null context");                    \
+        if (!(c)->have_state) return fail(SPHHIP_ESTATE, "no particles uploaded"); \
         HIP_TRY(hipSetDevice((c)->device));                                      \
     } while (0)
 
@@ -592,6 +601,25 @@ extern "C" int sphhip_step(SphCtx* c, float mx, float my, float strength, int ns
         if (rc) return rc;
     }
     return SPHHIP_OK;
+}
+
+// One step in two halves for the slab driver: begin = grid build, density, and the force / integrate pass of
+// the ghost columns and of the first `edge_left` / last `edge_right` owned columns; finish = the same pass
+// over the interior columns.  In between the caller packs the halo messages (sphhip_pack_halo_async reads
+// only columns begin has finished) and starts their exchange, which then overlaps the interior pass.
+extern "C" int sphhip_step_begin(SphCtx* c, float mx, float my, float strength, int edge_left, int edge_right) {
+    NEED_STATE(c);
+    if (edge_left < 0 || edge_right < 0) return fail(SPHHIP_EINVAL, "sphhip_step_begin: negative edge width");
+    int rc = sph_grid_build(c, false);
+    if (rc) return rc;
+    rc = sph_density_launch(c);
+    if (rc) return rc;
+    return sph_force_launch(c, mx, my, strength, true, 1, edge_left, edge_right);
+}
+
+extern "C" int sphhip_step_finish(SphCtx* c) {
+    NEED_STATE_MIDSTEP(c);
+    return sph_force_launch(c, c->split.mx, c->split.my, c->split.strength, true, 2);
 }
 
 extern "C" int sphhip_step_reference_order(SphCtx* c, float mx, float my, float strength, int nsteps) {
@@ -934,7 +962,7 @@ static int split_impl(SphCtx* c, int send_hi_left, int send_lo_right, int keep_l
 
 extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_right, void* d_msg_left,
                                       void* d_msg_right, int cap) {
-    NEED_STATE(c);
+    NEED_STATE_MIDSTEP(c);
     if (cap < 0) return fail(SPHHIP_EINVAL, "sphhip_pack_halo_async: negative capacity");
     HaloRec* l = (HaloRec*)d_msg_left;
     HaloRec* r = (HaloRec*)d_msg_right;

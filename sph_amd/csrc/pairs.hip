@@ -973,8 +973,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
     DevConsts c, const float2* __restrict__ pos, const float2* __restrict__ vel, const float* __restrict__ rho,
     const float* __restrict__ prs, const uint32_t* __restrict__ idv, const uint32_t* __restrict__ skeys,
     const int* __restrict__ cell_start, float2* __restrict__ pos_o, float2* __restrict__ vel_o, TileQueue q, int col_lo,
-    int col_hi, int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my, float strength,
-    int allow_fast, const uint32_t* __restrict__ nmask, int n_max, DenseSink sink) {
+    int col_hi, int skip_lo, int skip_hi, int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my,
+    float strength, int allow_fast, const uint32_t* __restrict__ nmask, int n_max, DenseSink sink) {
     extern __shared__ __align__(16) float4 s_dyn[];
     PairRec* s_rec = reinterpret_cast<PairRec*>(s_dyn);
     int* s_off = reinterpret_cast<int*>(s_rec + cap);
@@ -982,7 +982,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
     int* s_wave = s_gs + PAIR_MAXC;
     uint8_t* s_q = reinterpret_cast<uint8_t*>(s_wave + 8);
     for_each_tile(q, [&](int col, int trow, int tix) {
-        if (col < col_lo || col >= col_hi) return;
+        // columns [col_lo, col_hi) without [skip_lo, skip_hi): a slab step runs the columns next to the slab
+        // boundaries first and the interior in a second launch (sph_force_launch)
+        if (col < col_lo || col >= col_hi || (col >= skip_lo && col < skip_hi)) return;
         force_tile<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, col, trow, tile_cells, cap,
                                   own_lo_col, own_hi_col, mx, my, strength, allow_fast, nmask, n_max, sink, s_rec, s_off,
                                   s_gs, s_wave, s_q, tix);
@@ -1621,21 +1623,31 @@ int sph_density_launch(SphCtx* c) {
     return SPHHIP_OK;
 }
 
-int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate) {
+// part 0: the whole pass.  Parts 1 and 2 split a fused pass for the slab step: part 1 runs the ghost columns
+// and the first `edge_l` / last `edge_r` owned columns -- everything the halo messages of the next step are
+// packed from -- and swaps the state buffers; part 2 runs the remaining (interior) columns from the old
+// buffers into the new ones while the messages travel.  Between the two only sphhip_pack_halo_async may be
+// called (SphCtx::split.pending).
+int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate, int part, int edge_l, int edge_r) {
+    const bool second = part == 2;
+    if (second && !c->split.pending) return SPHHIP_OK;
     if (sph_n_grid(c) == 0) return SPHHIP_OK;
     PhaseScope ps(c, SPHHIP_PH_FORCE);
     // owned columns plus the halo on each side (ghost tiles pass their particles through); on a slab
     // every particle lies inside that range (sphhip_pack_halo keeps nothing farther out)
     const int flo = c->col_lo - SPHHIP_HALO_COLS > 0 ? c->col_lo - SPHHIP_HALO_COLS : 0;
     const int fhi = c->col_hi + SPHHIP_HALO_COLS < c->dc.nx ? c->col_hi + SPHHIP_HALO_COLS : c->dc.nx;
+    int il = second ? c->split.il : c->col_lo + edge_l, ih = second ? c->split.ih : c->col_hi - edge_r;
+    if (part == 1 && (il >= ih || !fuse_integrate)) part = 0;  // no interior: one launch does it all
     TileQueue q;
     int rc = ensure_tile_list(c, q);
     if (rc) return rc;
     const int th = c->pair_threads;
     size_t lds = pair_lds_bytes(c->pair_cap, true, th);
     // the masks of the last density pass describe this grid and this tiling
-    const bool masks_ok = c->use_masks && c->counts_valid && c->grid_valid && c->mask_tile_cells == c->tile_cells &&
-                          c->mask_cap == c->pair_cap;
+    const bool masks_ok = second ? c->split.masks_ok
+                                 : c->use_masks && c->counts_valid && c->grid_valid && c->mask_tile_cells == c->tile_cells &&
+                                       c->mask_cap == c->pair_cap;
     auto kern = fuse_integrate ? (th == 128 ? k_force<true, 128> : k_force<true, 256>)
                                : (th == 128 ? k_force<false, 128> : k_force<false, 256>);
     int grid = 0;
@@ -1645,23 +1657,40 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     int dense_grid = 0;
     bool tp = false;
     if ((rc = dense_prepare(c, 1, sink, dq, dense_grid, tp))) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv,
-                       c->keys, c->cell_start, c->pos2, c->vel2, q, flo, fhi, c->tile_cells, c->pair_cap, c->col_lo,
-                       c->col_hi, mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr,
-                       c->n_max, sink);
+    // (part 2 runs after part 1 has swapped the buffers: it reads the old state, now in pos2 / vel2)
+    const float2 *pin = second ? c->pos2 : c->pos, *vin = second ? c->vel2 : c->vel;
+    float2 *pout = second ? c->pos : c->pos2, *vout = second ? c->vel : c->vel2;
+    const int lo = second ? il : flo, hi = second ? ih : fhi;
+    const int skip_lo = part == 1 ? il : 0, skip_hi = part == 1 ? ih : 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
+                       c->cell_start, pout, vout, q, lo, hi, skip_lo, skip_hi, c->tile_cells, c->pair_cap, c->col_lo, c->col_hi,
+                       mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink);
     LAUNCH_CHECK();
     if (sink.defer) {
         auto dkern = tp ? (fuse_integrate ? k_force_dense_tp<true> : k_force_dense_tp<false>)
                         : (fuse_integrate ? k_force_dense<true> : k_force_dense<false>);
         hipLaunchKernelGGL(dkern, dim3(dense_grid), dim3(DENSE_THREADS), pair_lds_bytes(c->pair_cap, true, DENSE_THREADS),
-                           c->stream, c->dc, c->pos, c->vel, c->rho, c->prs, c->idv, c->keys, c->cell_start, c->pos2, c->vel2,
-                           dq, c->pair_cap, mx, my, strength, c->fast_div ? 1 : 0);
+                           c->stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys, c->cell_start, pout, vout, dq,
+                           c->pair_cap, mx, my, strength, c->fast_div ? 1 : 0);
         LAUNCH_CHECK();
+    }
+    if (second) {
+        c->split.pending = false;
+        return SPHHIP_OK;
     }
     std::swap(c->vel, c->vel2);
     if (fuse_integrate) {
         std::swap(c->pos, c->pos2);
         c->grid_valid = false;
+    }
+    if (part == 1) {
+        c->split.pending = true;
+        c->split.masks_ok = masks_ok;
+        c->split.il = il;
+        c->split.ih = ih;
+        c->split.mx = mx;
+        c->split.my = my;
+        c->split.strength = strength;
     }
     return SPHHIP_OK;
 }

@@ -116,6 +116,13 @@ struct SphCtx {
     std::vector<uint64_t> step_graph_sig;        // host state the graph was captured in (and returns to)
     bool graph_off = false;                      // SPHHIP_GRAPH=0, or a capture failed
 
+    // a fused force pass split in two launches (sphhip_step_begin / sphhip_step_finish): the interior is still to run
+    struct {
+        bool pending = false, masks_ok = false;
+        int il = 0, ih = 0;  // interior columns
+        float mx = 0, my = 0, strength = 0;
+    } split;
+
     bool profiling = false;
     unsigned profile_mask = ~0u;  // bit ph: bracket that phase with events
     PhaseTimer timer;
@@ -141,7 +148,8 @@ int sph_hip_fail(hipError_t e, const char* what, const char* file, int line);
 int sph_grid_build(SphCtx* c, bool carry_density);
 int sph_density_launch(SphCtx* c);
 void sph_adapt_tile_cells(SphCtx* c, int n);  // pairs.hip: tile height for the coming grid build
-int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate);
+int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate, int part = 0, int edge_l = 0,
+                     int edge_r = 0);
 int sph_integrate_launch(SphCtx* c);
 int sph_step_reference_order(SphCtx* c, float mx, float my, float strength, int nsteps);
 int sph_set_n_host(SphCtx* c, int n);

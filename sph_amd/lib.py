@@ -36,6 +36,8 @@ SIGNATURES = {
     "sphhip_forces": [_vp, _cf, _cf, _cf],
     "sphhip_integrate": [_vp],
     "sphhip_step": [_vp, _cf, _cf, _cf, _ci],
+    "sphhip_step_begin": [_vp, _cf, _cf, _cf, _ci, _ci],
+    "sphhip_step_finish": [_vp],
     "sphhip_step_reference_order": [_vp, _cf, _cf, _cf, _ci],
     "sphhip_get_cells": [_vp, _vp, _vp, _vp, _vp],
     "sphhip_get_neighbor_counts": [_vp, _vp, _ci],

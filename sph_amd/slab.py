@@ -17,6 +17,8 @@ Results are identical to the single-GPU path bit for bit: the sorted order is ca
 (key, id) whatever order particles arrive in, ghosts are sorted into the same cells, and every
 owned particle sums the same neighbours in the same order.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -29,6 +31,9 @@ HALO_COLS = 2  # SPHHIP_HALO_COLS
 # A slab must be wider than the halo: a particle that enters a neighbour's slab from its far side
 # must not land inside my ghost range in the same step (it would reach me one step late).
 MIN_SLAB_COLS = HALO_COLS + 1
+# The halo messages are packed from the first / last PACK_REACH owned columns (a particle crosses less than
+# one column per step: sphhip_pack_halo_async, ctx.hip): what step_begin has to finish before the pack.
+PACK_REACH = HALO_COLS + 1
 BIG = 0x7FFFFFFF
 
 
@@ -111,6 +116,14 @@ class HipSlabBackend:
     def step(self, mouse, strength):
         self.solver.stepSimulation(mouse, strength, 1)
 
+    def step_begin(self, mouse, strength, has_left, has_right):
+        """Everything of a step that the next halo messages depend on (the columns within PACK_REACH of a
+        slab boundary); step_finish() runs the interior."""
+        self.solver.stepBegin(mouse, strength, PACK_REACH if has_left else 0, PACK_REACH if has_right else 0)
+
+    def step_finish(self):
+        self.solver.stepFinish()
+
     def drop_ghosts(self):
         self.solver.drop_ghosts()
 
@@ -139,6 +152,7 @@ class SlabSolver:
         # under nccl (RCCL) the device buffers go straight over xGMI
         self.stage_cpu = dist.get_backend(group) == "gloo"
         self._ops_cache = {}
+        self.overlap = os.environ.get("SPH_SLAB_OVERLAP", "1") != "0"  # exchange overlapped with the interior columns
         self.set_bounds(bounds)
 
     # -- partition ----------------------------------------------------------------------------
@@ -162,13 +176,15 @@ class SlabSolver:
         return self.bounds
 
     # -- halo exchange + migration ------------------------------------------------------------
-    def _exchange(self, left, right, recv_l, recv_r):
-        """One fixed-size message per direction (header + records); no count round trip."""
+    def _exchange_start(self, left, right, recv_l, recv_r):
+        """One fixed-size message per direction (header + records); no count round trip.  Returns what
+        _exchange_wait needs: the transfers are in flight (RCCL: on the communicator's own stream, ordered
+        behind what the current stream has enqueued so far)."""
         r = self.rank
         stage = self.stage_cpu and (left if left is not None else right) is not None and \
             (left if left is not None else right).device.type != "cpu"
+        out_l, out_r = recv_l, recv_r
         if stage:
-            out_l, out_r = recv_l, recv_r
             left = left.cpu() if left is not None else None
             right = right.cpu() if right is not None else None
             recv_l = torch.empty(recv_l.shape, dtype=recv_l.dtype) if left is not None else None
@@ -186,28 +202,51 @@ class SlabSolver:
                         dist.P2POp(dist.irecv, recv_r, self._peer(r + 1), self.group)]
             if not stage:
                 self._ops_cache = {key: ops}
-        if ops:
-            for q in dist.batch_isend_irecv(ops):
-                q.wait()
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, stage, (left, right, recv_l, recv_r, out_l, out_r)
+
+    def _exchange_wait(self, handle):
+        works, stage, (left, right, recv_l, recv_r, out_l, out_r) = handle
+        for q in works:
+            q.wait()  # RCCL: the current stream waits, the host does not
         if stage:
             if left is not None:
                 out_l.copy_(recv_l)
             if right is not None:
                 out_r.copy_(recv_r)
 
+    def _exchange(self, left, right, recv_l, recv_r):
+        self._exchange_wait(self._exchange_start(left, right, recv_l, recv_r))
+
     def _peer(self, group_rank):
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
 
     def step(self, nsteps=1, mouse=(0.0, 0.0), strength=0.0):
+        """nsteps steps.  Before the first one the halo is exchanged on its own; between two steps of the
+        same call the exchange overlaps the step: the backend first finishes the columns next to the slab
+        boundaries (step_begin), the messages are packed from them and sent while the interior columns
+        are computed (step_finish).  The state at return is that after a whole step, as if every step had
+        been exchange, append, step."""
         has_l, has_r = self.rank > 0, self.rank < self.world - 1
-        for _ in range(nsteps):
-            send_hi_left = self.c0 + HALO_COLS if has_l else -1
-            send_lo_right = self.c1 - HALO_COLS if has_r else BIG
+        send_hi_left = self.c0 + HALO_COLS if has_l else -1
+        send_lo_right = self.c1 - HALO_COLS if has_r else BIG
+        split = self.overlap and hasattr(self.backend, "step_begin") and (has_l or has_r)
+        for i in range(nsteps):
+            if i == 0 or not split:
+                left, right = self.backend.pack(send_hi_left, send_lo_right, has_l, has_r)
+                recv_l, recv_r = self.backend.recv_buffers()
+                self._exchange(left, right, recv_l, recv_r)
+                self.backend.finish(has_l, has_r)
+            if not split or i == nsteps - 1:
+                self.backend.step(mouse, strength)
+                continue
+            self.backend.step_begin(mouse, strength, has_l, has_r)
             left, right = self.backend.pack(send_hi_left, send_lo_right, has_l, has_r)
             recv_l, recv_r = self.backend.recv_buffers()
-            self._exchange(left, right, recv_l, recv_r)
+            handle = self._exchange_start(left, right, recv_l, recv_r)
+            self.backend.step_finish()
+            self._exchange_wait(handle)
             self.backend.finish(has_l, has_r)
-            self.backend.step(mouse, strength)
 
     # -- state --------------------------------------------------------------------------------
     def download_local(self):

@@ -82,6 +82,13 @@ class Solver:
     def stepSimulation(self, mousePos=(0.0, 0.0), interactionStrength=0.0, nsteps=1):
         _lib.check(self.L.sphhip_step(self.h, mousePos[0], mousePos[1], interactionStrength, int(nsteps)))
 
+    def stepBegin(self, mousePos=(0.0, 0.0), interactionStrength=0.0, edge_left=0, edge_right=0):
+        """First half of a step (sphhip_step_begin): everything but the force pass of the interior columns."""
+        _lib.check(self.L.sphhip_step_begin(self.h, mousePos[0], mousePos[1], interactionStrength, edge_left, edge_right))
+
+    def stepFinish(self):
+        _lib.check(self.L.sphhip_step_finish(self.h))
+
     def stepSimulationReferenceOrder(self, mousePos=(0.0, 0.0), interactionStrength=0.0, nsteps=1):
         """serial_stepSimulation (SPH/sph.cpp:166-171) with the reference's own all-pairs order and in-place
         velocity update: sequential parity tool for n <= 4096, bit-exact against the reference's serial path."""

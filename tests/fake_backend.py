@@ -99,6 +99,12 @@ class FakeSlabBackend:
             self.a[f][~owned] = before[f][~owned]
         self.owned_mask = owned
 
+    def step_begin(self, mouse, strength, has_left, has_right):
+        self.step(mouse, strength)  # (the oracle has no halves: everything is finished before the pack)
+
+    def step_finish(self):
+        pass
+
     def download(self):
         o = np.argsort(self.ids, kind="stable")
         return self.a[o].copy(), self.ids[o].astype(np.int32)
