@@ -212,7 +212,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total * args.steps / elapsed
         f_ms, f_k = phases["force"]
-        force_avg_s = (f_ms / max(f_k, 1)) * 1e-3
+        # per step, not per launch: a slab step with neighbours runs the pass as two launches (boundary columns, interior)
+        force_avg_s = (f_ms / max(min(f_k, args.steps), 1)) * 1e-3
         achieved = FORCE_BYTES_PER_PARTICLE * n_local / force_avg_s / 1e9 if force_avg_s > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
