@@ -390,6 +390,24 @@ def test_random_scenes_fuzz(seed):
     assert orc.same_bits_nan(got, want)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_scaled_scenes_fuzz(seed):
+    """Dam-break / box miniatures with jitter and random velocities, 1-40 steps in ONE call (graph replay and
+    the one-workgroup grid build for the small ones), against the oracle."""
+    rng = np.random.default_rng(5000 + seed)
+    cols = int(rng.choice([8, 20, 33, 64, 100, 150]))
+    params, a = scenes.dam_break(cols, int(rng.integers(4, cols + 1))) if seed % 2 else scenes.uniform_box(cols)
+    a["pos"] += rng.uniform(-0.01, 0.01, size=a["pos"].shape).astype(np.float32)
+    a["vel"] = rng.normal(0.0, float(rng.choice([0.0, 0.5, 3.0])), size=a["vel"].shape).astype(np.float32)
+    steps = int(rng.choice([1, 7, 18, 27, 40]))
+    want = O.step_cells(params, a.copy(), steps)
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.stepSimulation(nsteps=steps)
+        got = s.download()
+    assert orc.same_bits_nan(got, want)
+
+
 def test_full_size_dam_break_bit_exact():
     """BASELINE configs[1] at full size (1M-particle dam break): the cell-list oracle finishes a step in a
     fraction of a second, so the whole state is compared bit for bit after 3 steps, the neighbour counts
