@@ -76,14 +76,15 @@ def test_hip_slabs_equal_single_gpu(tmp_path, world, nsteps):
     assert orc.same_bits(got, orc.Oracle().step_cells(params, a.copy(), nsteps))
 
 
-def test_hip_slabs_dense_scene(tmp_path):
-    """Two slabs of the reference box at N=8192 (dense sub-tiles, adapted tile height, ghost columns that
+@pytest.mark.parametrize("world", [2, 3])
+def test_hip_slabs_dense_scene(tmp_path, world):
+    """Two / three slabs of the reference box at N=8192 (dense sub-tiles, adapted tile height, ghost columns that
     are dense themselves), particles streaming across the boundary in both directions."""
     from sph_amd.solver import Solver
 
     out = str(tmp_path / "got.npy")
     nsteps = 24
-    mp.spawn(_worker, args=(2, _free_port(), nsteps, out, "dense"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), nsteps, out, "dense"), nprocs=world, join=True)
     got = np.load(out)
     params, a = _scene("dense")
     with Solver(params, n_max=len(a)) as s:
