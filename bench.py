@@ -147,7 +147,8 @@ def main():
         # weak scaling: the fluid column gets `world` times wider, per-GPU particle count fixed;
         # strong scaling: the named scene as it is, split into `world` slabs
         total_cols = cols * world if args.scaling == "weak" else cols
-        params, n_total, hist_fn, make_local = scenes.dam_break_sharded(total_cols, rows)
+        sharded = scenes.dam_break_sharded if kind == "dam" else scenes.uniform_box_sharded
+        params, n_total, hist_fn, make_local = sharded(total_cols, rows)
         drv = _lib.derive(params)
         solver = make_hip_slab(params, make_local, local_rank, hist=hist_fn(drv))
         step = lambda k: solver.step(nsteps=k)  # noqa: E731
@@ -245,7 +246,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "2D dam-break, %d particles (%d x %d lattice at spacing H/4, box %.1f x %.1f, sph.h constants), fp32"
+                "workload": "2D %s, %%d particles (%%d x %%d lattice at spacing H/4, box %%.1f x %%.1f, sph.h constants), fp32"
+                % ("dam-break" if kind == "dam" else "uniform box filled wall to wall")
                 % (n_total, n_total // rows, rows, params.xmax - params.xmin, params.ymax - params.ymin),
                 "name": name,
                 "particles": n_total,

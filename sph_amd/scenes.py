@@ -86,17 +86,8 @@ def uniform_box(side, spacing=None, base=None):
     return p, a
 
 
-def dam_break_sharded(cols, rows=None, spacing=None, base=None):
-    """The dam-break scene for slab-decomposed runs: returns (params, n_total, column_hist_fn,
-    make_local) where make_local(c0, c1, drv) generates only the particles whose grid column is in
-    [c0, c1) together with their global ids (id = row * cols + col, as `dam_break` numbers them)."""
-    rows = rows or cols
-    base = base or SphParams.reference()
-    sp = F(spacing) if spacing else F(base.h / F(4.0))
-    w = F(F(cols) * sp)
-    # box: 4 x the fluid width, 2 x the fluid height (for cols == rows exactly `dam_break`'s box); the
-    # height does not grow with the number of slabs, so weak scaling keeps the per-rank grid work fixed
-    p = _params_for_box(F(4.0) * w, F(2.0) * F(F(rows) * sp), base)
+def _lattice_sharded(p, cols, rows, sp, base):
+    """cols x rows lattice from (xmin, ymin) at spacing sp, generated slab by slab: see dam_break_sharded."""
     xs = (F(p.xmin) + np.arange(cols).astype(np.float32) * sp).astype(np.float32)
     ys = (F(p.ymin) + np.arange(rows).astype(np.float32) * sp).astype(np.float32)
 
@@ -121,3 +112,28 @@ def dam_break_sharded(cols, rows=None, spacing=None, base=None):
         return a, ids
 
     return p, cols * rows, column_hist, make_local
+
+
+def dam_break_sharded(cols, rows=None, spacing=None, base=None):
+    """The dam-break scene for slab-decomposed runs: returns (params, n_total, column_hist_fn,
+    make_local) where make_local(c0, c1, drv) generates only the particles whose grid column is in
+    [c0, c1) together with their global ids (id = row * cols + col, as `dam_break` numbers them)."""
+    rows = rows or cols
+    base = base or SphParams.reference()
+    sp = F(spacing) if spacing else F(base.h / F(4.0))
+    w = F(F(cols) * sp)
+    # box: 4 x the fluid width, 2 x the fluid height (for cols == rows exactly `dam_break`'s box); the
+    # height does not grow with the number of slabs, so weak scaling keeps the per-rank grid work fixed
+    p = _params_for_box(F(4.0) * w, F(2.0) * F(F(rows) * sp), base)
+    return _lattice_sharded(p, cols, rows, sp, base)
+
+
+def uniform_box_sharded(cols, rows=None, spacing=None, base=None):
+    """`uniform_box` for slab-decomposed runs (cols x rows lattice filling its box wall to wall; weak scaling
+    widens the box with the rank count): same return value as dam_break_sharded."""
+    rows = rows or cols
+    base = base or SphParams.reference()
+    sp = F(spacing) if spacing else F(base.h / F(4.0))
+    p = _params_for_box(F(F(cols - 1) * sp), F(F(rows - 1) * sp), base)
+    return _lattice_sharded(p, cols, rows, sp, base)
+
