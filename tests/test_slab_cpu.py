@@ -26,7 +26,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, scene, nsteps, rebalance_every, out_path):
+def _worker(rank, world, port, scene, nsteps, rebalance_every, out_path, overlap="1"):
+    os.environ["SPH_SLAB_OVERLAP"] = overlap
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -39,13 +40,15 @@ def _worker(rank, world, port, scene, nsteps, rebalance_every, out_path):
         hist = np.bincount(grid_column(a["pos"][:, 0], params, backend.drv), minlength=backend.drv.nx)
         slab = SlabSolver(backend, params, balanced_bounds(hist, world))
         distribute(slab, a)
-        moved = 0
-        for s in range(nsteps):
-            if rebalance_every and s and s % rebalance_every == 0:
+        # several steps per call: between the steps of one call the exchange is overlapped with the step
+        # (step_begin / pack / step_finish), the first exchange of a call is not
+        done = 0
+        while done < nsteps:
+            if rebalance_every and done:
                 slab.rebalance()
-            before = backend.n
-            slab.step(1)
-            moved += abs(backend.n - before)
+            k = min(rebalance_every or nsteps, nsteps - done)
+            slab.step(k)
+            done += k
         got = slab.gather(len(a))
         if rank == 0:
             np.save(out_path, got)
@@ -64,11 +67,12 @@ def _scene(name):
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("world,scene,nsteps,rebalance_every", [(2, "dam", 6, 0), (3, "sloshing", 40, 0),
-                                                                 (2, "sloshing", 30, 7)])
-def test_slab_equals_single_domain(tmp_path, world, scene, nsteps, rebalance_every):
+@pytest.mark.parametrize("world,scene,nsteps,rebalance_every,overlap", [(2, "dam", 6, 0, "1"), (3, "sloshing", 40, 0, "1"),
+                                                                         (2, "sloshing", 30, 7, "1"),
+                                                                         (2, "sloshing", 30, 7, "0"), (2, "dam", 5, 1, "1")])
+def test_slab_equals_single_domain(tmp_path, world, scene, nsteps, rebalance_every, overlap):
     out = str(tmp_path / "got.npy")
-    mp.spawn(_worker, args=(world, _free_port(), scene, nsteps, rebalance_every, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), scene, nsteps, rebalance_every, out, overlap), nprocs=world, join=True)
     got = np.load(out)
     params, a = _scene(scene)
     want = orc.Oracle().step_cells(params, a.copy(), nsteps)
