@@ -376,6 +376,7 @@ extern "C" int sphhip_upload(SphCtx* c, const void* aos28, int n, int id_base) {
     }
     HIP_TRY(hipStreamSynchronize(c->stream));  // the host buffer is only borrowed for the call
     c->have_state = true;
+    c->split.pending = false;  // (a new state: nothing of an unfinished step is left)
     c->grid_valid = false;
     c->counts_valid = false;
     c->slice_valid = false;
@@ -387,6 +388,7 @@ extern "C" int sphhip_upload(SphCtx* c, const void* aos28, int n, int id_base) {
 static int download_impl(SphCtx* c, void* aos28, int* ids, int n) {
     if (!c || (!aos28 && n > 0)) return fail(SPHHIP_EINVAL, "sphhip_download: null argument");
     if (!c->have_state) return fail(SPHHIP_ESTATE, "sphhip_download: nothing uploaded");
+    if (c->split.pending) return fail(SPHHIP_ESTATE, "sphhip_download: sphhip_step_begin without sphhip_step_finish");
     HIP_TRY(hipSetDevice(c->device));
     {
         int rc = sph_sync_n(c);

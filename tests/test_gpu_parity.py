@@ -408,6 +408,29 @@ def test_scaled_scenes_fuzz(seed):
     assert orc.same_bits_nan(got, want)
 
 
+def test_step_in_two_halves(solver):
+    """sphhip_step_begin + sphhip_step_finish = sphhip_step(1), whatever the edge widths; nothing but the
+    halo pack may be called in between."""
+    from sph_amd.lib import SphHipError
+
+    a = G("f2_serial_traj_n1024")["s50"]
+    solver.upload(a)
+    solver.stepSimulation((0.8, 0.9), 50000.0, 3)
+    want = solver.download()
+    for edges in ((3, 3), (0, 5), (1, 0), (0, 0), (40, 40)):
+        solver.upload(a)
+        for _ in range(3):
+            solver.stepBegin((0.8, 0.9), 50000.0, *edges)
+            if 0 < sum(edges) < 20:  # (no interior, or no edge: begin did it all)
+                with pytest.raises(SphHipError):
+                    solver.stepSimulation(nsteps=1)
+                with pytest.raises(SphHipError):
+                    solver.download()
+            solver.stepFinish()
+        assert orc.same_bits(solver.download(), want), edges
+    solver.stepFinish()  # without a begin: nothing to do
+
+
 def test_full_size_dam_break_bit_exact():
     """BASELINE configs[1] at full size (1M-particle dam break): the cell-list oracle finishes a step in a
     fraction of a second, so the whole state is compared bit for bit after 3 steps, the neighbour counts
