@@ -1,4 +1,5 @@
-"""Runs tests/test_gpu_parity.py::test_random_scenes_fuzz for a range of extra seeds (GPU box)."""
+"""Test infrastructure (uses the oracle): runs the fuzz tests of tests/test_gpu_parity.py for a range of extra seeds on the GPU box:
+    python tests/debug/fuzz_many.py <first seed> <last seed + 1> [box|scaled]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
