@@ -223,6 +223,11 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     ok(dmalloc(&c->nmask, n * 8));
     ok(dmalloc(&c->keys, n)); ok(dmalloc(&c->keys2, n)); ok(dmalloc(&c->perm, n)); ok(dmalloc(&c->perm2, n));
     ok(dmalloc(&c->ids_sorted, n));
+    if (e == hipSuccess) {  // index arrays start defined: a stale entry must never be an out-of-range index
+        for (void* p : {(void*)c->keys, (void*)c->keys2, (void*)c->perm, (void*)c->perm2, (void*)c->ids_sorted, (void*)c->idv,
+                        (void*)c->idv2})
+            ok(hipMemset(p, 0, sizeof(uint32_t) * std::max<size_t>(n, 1)));
+    }
     {   // two cell tables, each followed by the partial sums of its scan (see grid.hip)
         const size_t words = (size_t)c->ncell + 1 + ((size_t)c->ncell + 1 + 2047) / 2048 + 8;
         for (int b = 0; b < 2; b++) {
@@ -237,7 +242,9 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     ok(dmalloc(&c->digit_total, 2 * SORT_RADIX));
     ok(dmalloc(&c->scan_tmp, (size_t)(c->ncell + 1 + 2047) / 2048 + 1));
     ok(dmalloc(&c->counters, 64));
-    ok(dmalloc(&c->tile_list, (size_t)c->ncell + c->ncell / 64 + 64));
+    c->tile_list_cap = c->ncell + c->ncell / 64 + 64;
+    ok(dmalloc(&c->tile_list, (size_t)c->tile_list_cap));
+    if (e == hipSuccess) ok(hipMemset(c->tile_list, 0, sizeof(int) * (size_t)c->tile_list_cap));
     ok(hipHostMalloc((void**)&c->h_host_tiles, 2 * sizeof(int), hipHostMallocMapped));
     if (e == hipSuccess) {
         c->h_host_tiles[0] = -1;

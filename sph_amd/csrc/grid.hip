@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
                                                        float* __restrict__ prs_o, uint32_t* __restrict__ idv_o,
                                                        int reorder_blocks, TileListArgs tl, int ny,
                                                        int* __restrict__ zero_buf, int zero_words,
-                                                       int* __restrict__ zero_buf2, int zero_words2) {
+                                                       int* __restrict__ zero_buf2, int zero_words2, int ncell) {
     if ((int)blockIdx.x >= reorder_blocks) {
         // tail workgroups: list the non-empty tiles of the pair kernels for this grid, and zero the idle
         // cell table for the next build -- two small launches saved per step
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     uint32_t k = skeys[s];
+    if (k >= (uint32_t)ncell) return;  // (never for a slot below the count; a stale key must not become an address)
     int a = cell_start[k], b = cell_start[k + 1];
     uint32_t my = ids_sorted[s];
     int rank = 0;
@@ -632,6 +633,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     const int r_parts = (r_len + SCAN_CHUNK - 1) / SCAN_CHUNK;
     bool range_moved = false;
     bool fused = false;  // k_grid_small did the whole build
+    bool count_update = false;
     if (c->grid_counting) {
         {
             PhaseScope ps(c, SPHHIP_PH_HASH);
@@ -648,7 +650,12 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             c->cell_cur = next;
             c->cell_start = c->cell_buf[next];
             c->cell_next_zeroed = false;
-            fused = n > 0 && n <= SMALL_MAX_N && r_len <= SMALL_MAX_CELLS && !prev_table && !c->pending_drop && c->small_grid;
+            // The build can drop particles: the stale ghosts of a pending drop, and -- on a slab, whose cell table
+            // covers only its own column range -- any particle outside that range (a non-finite position has
+            // column 0).  Then the scan's total, not the old count, is the particle count from here on: the
+            // slots behind it hold nothing (k_rank_reorder must not read their keys).
+            count_update = c->pending_drop || clo > 0 || chi < c->dc.nx;
+            fused = n > 0 && n <= SMALL_MAX_N && r_len <= SMALL_MAX_CELLS && !prev_table && !count_update && c->small_grid;
             if (fused) {
                 TileListArgs tl = {};
                 int lo = 0, hi = 0;
@@ -675,7 +682,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
                                c->cell_start + len);
             hipLaunchKernelGGL(k_scan_apply, dim3(r_parts), dim3(256), 0, st, c->cell_start + r_first, r_len, c->cell_start + len,
                                c->counters + SPH_TILE_COUNT_SLOT, c->counters + SPH_N_SORTED_SLOT,
-                               c->pending_drop ? sph_n_slot_next(c) : (int*)nullptr);
+                               count_update ? sph_n_slot_next(c) : (int*)nullptr);
             LAUNCH_CHECK();
         }
         if (n > 0 && !fused) {
@@ -684,7 +691,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
                                c->cell_start, c->keys, c->perm, c->ids_sorted);
             LAUNCH_CHECK();
         }
-        if (c->pending_drop) {  // the scan wrote the count without the dropped ghosts into the next ring slot
+        if (count_update) {  // the scan wrote the count without the dropped particles into the next ring slot
             sph_n_advance(c);
             c->n_exact = false;
             c->pending_drop = false;
@@ -753,11 +760,11 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
         } else if (carry_density)
             hipLaunchKernelGGL(k_rank_reorder<true>, dim3(nb + tail), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
                                c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
-                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf + r_first, r_len, zero_buf + len, r_parts);
+                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf + r_first, r_len, zero_buf + len, r_parts, ncell);
         else
             hipLaunchKernelGGL(k_rank_reorder<false>, dim3(nb + tail), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
                                c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
-                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf + r_first, r_len, zero_buf + len, r_parts);
+                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf + r_first, r_len, zero_buf + len, r_parts, ncell);
         LAUNCH_CHECK();
         if (tail > 0 && range_moved) {  // the tail zeroed only the new range of the old table
             HIP_TRY(hipMemsetAsync(zero_buf, 0, sizeof(int) * (size_t)table_words, st));

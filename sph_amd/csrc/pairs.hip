@@ -1511,17 +1511,22 @@ static int ensure_tile_list(SphCtx* c, TileQueue& q) {
 // (plus slack; the kernels stride, so an underestimate only costs balance), else one resident wave of
 // workgroups.  Always a multiple of 8 (one chunk per XCD).
 static int pair_grid(SphCtx* c, const void* kern, int threads, size_t lds, int& grid) {
+    // Workgroup b reads list entry t(b) < grid before it knows the list length (for_each_tile): the grid must
+    // stay inside the list's allocation whatever the estimate says.
+    const int grid_max = c->tile_list_cap & ~7;
     const int est = ((volatile int*)c->h_host_tiles)[0], est_cells = ((volatile int*)c->h_host_tiles)[1];
     if (est >= 0 && est_cells > 0) {
         // (a count taken under another tiling is rescaled; any grid size is correct)
-        const long long e = est_cells == c->tile_cells ? est : ((long long)est * est_cells + c->tile_cells - 1) / c->tile_cells;
-        grid = (int)((e + e / 128 + 8 + 7) & ~7ll);
+        long long e = est_cells == c->tile_cells ? est : ((long long)est * est_cells + c->tile_cells - 1) / c->tile_cells;
+        e = (e + e / 128 + 8 + 7) & ~7ll;
+        grid = (int)std::min<long long>(e, grid_max);
         return SPHHIP_OK;
     }
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
     if (per_cu < 1) per_cu = 1;
     grid = (c->num_cus * per_cu) & ~7;
+    if (grid > grid_max) grid = grid_max;
     if (grid < 8) grid = 8;
     return SPHHIP_OK;
 }

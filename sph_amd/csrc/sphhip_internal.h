@@ -97,6 +97,7 @@ struct SphCtx {
     int* scan_tmp = nullptr;                     // block partials of the suffix-min scan
     int* counters = nullptr;                     // small device scratch (compaction counters ...)
     int* tile_list = nullptr;                    // non-empty tiles of the pair kernels (pairs.hip), <= ncell entries
+    int tile_list_cap = 0;                       // allocated entries (a pair-kernel grid never exceeds it: for_each_tile)
     bool tiles_valid = false;                    // ... current for this grid, tiles_cells, [tiles_lo, tiles_hi)
     int tiles_cells = 0, tiles_lo = 0, tiles_hi = 0;
     int num_cus = 256;
