@@ -94,3 +94,48 @@ def test_hip_slabs_dense_scene(tmp_path, world):
     assert orc.same_bits(got, single)
     assert orc.same_bits(got, orc.Oracle().step_cells(params, a.copy(), nsteps))
 
+
+def _nan_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from sph_amd.lib import SphHipError
+    from sph_amd.slab import make_hip_slab
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sph_amd.slab import records_from_particles
+
+        params, a = _scene()
+        slab = make_hip_slab(params, a[:-1], device=0)
+        if rank == world - 1:  # the last particle goes to the last rank, with a NaN position
+            bad = a[-1:].copy()
+            bad["pos"][:] = np.nan
+            slab.backend.append_host(records_from_particles(bad, [len(a) - 1]))
+        slab.step(4)
+        msg = ""
+        try:
+            slab.check()
+            slab.backend.drop_ghosts()
+            msg = "n=%d" % slab.backend.n
+        except SphHipError as e:
+            msg = str(e)
+        with open("%s.%d" % (out_path, rank), "w") as f:
+            f.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_non_finite_position_on_a_slab(tmp_path):
+    """A non-finite position has no column (the cell coordinate of NaN is 0).  Handed to the last rank, such a
+    particle is passed on to the left with every halo exchange and ends up on rank 0, which keeps it in cell 0
+    like a single domain does; had it turned NaN in an interior column, its slab would have dropped it in the
+    grid build and reported that (sticky out-of-slab error; tests/debug/fuzz_slab.py, seed 39).  Either way no
+    particle may be lost silently and no slot beyond the particle count may be read."""
+    out = str(tmp_path / "msg")
+    mp.spawn(_nan_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    msgs = [open("%s.%d" % (out, r)).read() for r in range(2)]
+    if all(m.startswith("n=") for m in msgs):
+        params, a = _scene()
+        assert sum(int(m[2:]) for m in msgs) == len(a)
+    else:
+        assert any("farther than the halo" in m for m in msgs)
