@@ -139,6 +139,9 @@ def main():
         from sph_amd import lib as _lib
         from sph_amd.slab import make_hip_slab
 
+        if world == 1:  # SPH_BENCH_FORCE_SLAB without a launcher: a one-rank group
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
         backend = os.environ.get("SPH_BENCH_BACKEND", "nccl")  # "gloo": debugging on a one-GPU box (host-staged messages)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -615,7 +615,8 @@ static inline int ilog2_ceil(unsigned v) {
 
 int sph_grid_build(SphCtx* c, bool carry_density) {
     const int n = sph_n_grid(c);  // exact count, or the capacity while the count is only known on the device
-    sph_adapt_tile_cells(c, n);
+    // (for the tile-height heuristic the last count the host saw beats the capacity)
+    sph_adapt_tile_cells(c, c->n_exact || c->n <= 0 ? n : c->n);
     hipStream_t st = c->stream;
     const int ncell = c->ncell;
     const int len = ncell + 1;
