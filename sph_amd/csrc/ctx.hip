@@ -267,6 +267,23 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     c->n_ring = c->counters + 32;
     c->d_n = c->n_ring;
     ok(hipMalloc(&c->staging, std::max<size_t>(n * SPHHIP_PARTICLE_BYTES, 64)));
+    if (e == hipSuccess && getenv("SPHHIP_POISON")) {
+        // debugging aid: data buffers start as 0xFF bytes (NaN floats, huge integers), so that a read of something
+        // never written shows up in the results instead of depending on what the allocator recycled.  The value
+        // is a bit mask: 1 pos/vel, 2 pos2/vel2, 4 rho/prs, 8 rho2/prs2, 16 ncount, 32 nmask, 64 staging.
+        const int which = atoi(getenv("SPHHIP_POISON"));
+        auto poison = [&](void* p, size_t bytes) { ok(hipMemset(p, 0xFF, bytes)); };
+        if (which & 1) for (float2* p : {c->pos, c->vel}) poison(p, sizeof(float2) * n);
+        if (which & 2) for (float2* p : {c->pos2, c->vel2}) poison(p, sizeof(float2) * n);
+        if (which & 4) for (float* p : {c->rho, c->prs}) poison(p, sizeof(float) * n);
+        if (which & 8) for (float* p : {c->rho2, c->prs2}) poison(p, sizeof(float) * n);
+        if (which & 16) poison(c->ncount, sizeof(int) * n);
+        if (which & 32) poison(c->nmask, sizeof(uint32_t) * n * 8);
+        if (which & 64) poison(c->staging, std::max<size_t>(n * SPHHIP_PARTICLE_BYTES, 64));
+    }
+    // the memsets above ran on the null stream, the context's own stream does not wait for it: finish them
+    // before anything (an upload) can be enqueued there
+    if (e == hipSuccess) ok(hipDeviceSynchronize());
     if (e != hipSuccess) {
         free_all(c);
         delete c;
