@@ -1,4 +1,5 @@
-"""Test infrastructure: one scene of the scaled fuzz (tests/test_gpu_parity.py::test_scaled_scenes_fuzz) in detail --\nwhich fields of which particles differ from the oracle:  python tests/debug/scaled_seed.py <seed>"""
+"""Test infrastructure: one scene of the scaled fuzz (tests/test_gpu_parity.py::test_scaled_scenes_fuzz) in detail --
+which fields of which particles differ from the oracle:  python tests/debug/scaled_seed.py <seed>"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
