@@ -86,6 +86,7 @@ struct HipMouseEvent {
 int HIP_main_scripted(int N, int steps, const HipMouseEvent* script, int n_events, int frame_every,
                       const char* frame_prefix, const char* dump_path);
 float HIP_performance_test(int N);
-// Last error text of the shim ("" if none); the reference's functions have no error channel, so
-// failures are reported here and on stderr, never by exit() (contrast SPH/sph.cuh:17-23).
+// Error text of the MOST RECENT shim call ("" if it succeeded: every call above clears it first); the
+// reference's functions have no error channel, so failures are reported here and on stderr, never by
+// exit() (contrast SPH/sph.cuh:17-23).
 const char* hip_lastError();

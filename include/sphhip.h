@@ -28,6 +28,10 @@ extern "C" {
 
 #define SPHHIP_PARTICLE_BYTES 28
 #define SPHHIP_HALO_COLS 2 /* ghost columns a slab needs on each side (see sphhip_pack_halo) */
+/* owned columns next to a slab boundary that the halo messages of the next step are packed from (a particle
+ * crosses less than one column per step): the edge widths sphhip_step_begin must be given on a side with a
+ * neighbour */
+#define SPHHIP_PACK_REACH (SPHHIP_HALO_COLS + 1)
 
 enum {
     SPHHIP_OK = 0,
@@ -130,7 +134,8 @@ int sphhip_count(SphCtx* ctx, int* n);
 
 /* ---- phases of the step (SPH/sph.h:35-39; device flavour SPH/sph.cuh:33-38) ------------ */
 
-/* Neighbour search: cell hash, LDS-local radix sort, cell start/end.  No counterpart in the
+/* Neighbour search: cell hash, sort by cell (one counting pass with LDS/wave-level run detection by default;
+ * SPHHIP_GRID=radix selects the LDS-local LSD radix sort), cell start/end.  No counterpart in the
  * reference beyond the dead `int* grid, int* cellStart, int* cellEnd` parameters of its kernels
  * (SPH/sph.cuh:33-34,38; always nullptr, SPH/sph.cu:222-223).  Reorders the device state into
  * (cell key, id) order. */
@@ -154,8 +159,9 @@ int sphhip_step(SphCtx* ctx, float mouse_x, float mouse_y, float strength, int n
  * full state before it computes).  sphhip_step_begin: grid, density, and the force + integrate pass of the
  * ghost columns and of the first edge_left / last edge_right owned columns -- everything the next halo
  * messages are packed from.  sphhip_step_finish: the same pass over the remaining owned columns.  Between
- * the two only sphhip_pack_halo_async (and stream / error queries) may be called; begin + finish give exactly
- * the state of sphhip_step(..., 1). */
+ * the two only sphhip_pack_halo_async (and stream / error queries) may be called, and only with send ranges
+ * inside the halo and edge widths >= SPHHIP_PACK_REACH on every side that has a message (SPHHIP_ESTATE
+ * otherwise); begin + finish give exactly the state of sphhip_step(..., 1). */
 int sphhip_step_begin(SphCtx* ctx, float mouse_x, float mouse_y, float strength, int edge_left, int edge_right);
 int sphhip_step_finish(SphCtx* ctx);
 

@@ -256,6 +256,7 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     // a particle is a candidate of at most 9 one-row sub-tiles; one entry per sub-tile and DENSE_THREADS own
     // particles: 9 n / 55 + n / 256 < n / 4 entries cover it
     c->dense_cap = n_max / 4 + 64;
+    if (const char* e = getenv("SPHHIP_DENSE_CAP")) c->dense_cap = std::max(1, atoi(e));  // (tests: force an overflow)
     ok(hipMalloc((void**)&c->dense_list, sizeof(int4) * (size_t)c->dense_cap));
     ok(hipHostMalloc((void**)&c->h_dense, 2 * sizeof(int), hipHostMallocMapped));
     if (e == hipSuccess) {
@@ -640,7 +641,13 @@ extern "C" int sphhip_step_begin(SphCtx* c, float mx, float my, float strength, 
     if (rc) return rc;
     rc = sph_density_launch(c);
     if (rc) return rc;
-    return sph_force_launch(c, mx, my, strength, true, 1, edge_left, edge_right);
+    // The pass is split only if the pack that follows can take its boundary-only path (it reads nothing but the
+    // columns this half finishes); otherwise the compacting split would run on a half-written state.  With
+    // SPHHIP_LAZY_PACK=0 / SPHHIP_GRID=radix the whole pass runs here and sphhip_step_finish has nothing to do.
+    const bool can_split = c->lazy_pack && c->grid_counting;
+    c->split.edge_l = edge_left;
+    c->split.edge_r = edge_right;
+    return sph_force_launch(c, mx, my, strength, true, can_split ? 1 : 0, edge_left, edge_right);
 }
 
 extern "C" int sphhip_step_finish(SphCtx* c) {
@@ -761,16 +768,17 @@ int sph_set_n_host(SphCtx* c, int n) {
 }
 
 int sph_sync_n(SphCtx* c) {
-    if (c->n_exact) return SPHHIP_OK;
-    int h[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(&h[0], c->d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // (the sticky error word is read whether or not the count is known: a single domain can raise it too, e.g.
+    // an overflow of the dense sub-tile list, pairs.hip: dense_defer)
+    int h[2] = {c->n, 0};
+    if (!c->n_exact) HIP_TRY(hipMemcpyAsync(&h[0], c->d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&h[1], c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n = h[0];
     c->n_exact = true;
     if (h[1]) {
         HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
-        if (h[1] & SPH_ERR_CAPACITY) return fail(SPHHIP_ECAPACITY, "particle capacity of the context exceeded during asynchronous steps (particles were dropped)");
+        if (h[1] & SPH_ERR_CAPACITY) return fail(SPHHIP_ECAPACITY, "a capacity of the context was exceeded during asynchronous steps (particle capacity: particles were dropped; dense sub-tile list: their particles were not updated)");
         if (h[1] & SPH_ERR_HALO_OVERFLOW) return fail(SPHHIP_ECAPACITY, "halo message buffer too small during asynchronous steps (records were dropped)");
         if (h[1] & SPH_ERR_OUT_OF_SLAB) return fail(SPHHIP_ESTATE, "particles farther than the halo from the owned columns were found (and dropped) by a grid build");
         return fail(SPHHIP_ECAPACITY, "received halo message with a bad record count");
@@ -998,7 +1006,11 @@ extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_r
         (!r || send_lo_right >= c->col_hi - SPHHIP_HALO_COLS)) {
         // fast path: the state is in the slot order of the last sort (a step has run since, nothing else)
         const int ny = c->dc.ny;
-        const int reach = SPHHIP_HALO_COLS + 1;  // a particle crosses less than one column per step
+        const int reach = SPHHIP_PACK_REACH;  // a particle crosses less than one column per step
+        // between the two halves of a step only the columns sphhip_step_begin finished hold the new state
+        if (c->split.pending && ((l && c->split.edge_l < reach) || (r && c->split.edge_r < reach)))
+            return fail(SPHHIP_ESTATE, "sphhip_pack_halo_async: sphhip_step_begin finished fewer than SPHHIP_PACK_REACH "
+                                       "columns on a side that has a message");
         const int l_hi = c->col_lo + reach < c->col_hi ? c->col_lo + reach : c->col_hi;
         const int r_lo = c->col_hi - reach > c->col_lo ? c->col_hi - reach : c->col_lo;
         hipLaunchKernelGGL(k_pack_boundary, dim3(2 * PACK_BLOCKS), dim3(256), 0, c->stream, c->dc, c->pos, c->vel, c->idv,
@@ -1010,6 +1022,10 @@ extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_r
         c->counts_valid = false;
         return SPHHIP_OK;
     }
+    // The compacting split reads and rewrites the whole state: not between the two halves of a step.
+    if (c->split.pending)
+        return fail(SPHHIP_ESTATE, "sphhip_pack_halo_async between sphhip_step_begin and sphhip_step_finish: the send ranges "
+                                   "exceed the halo (only the boundary-only pack may run there)");
     return split_enqueue(c, l ? send_hi_left : -1, r ? send_lo_right : 0x7fffffff, c->col_lo - SPHHIP_HALO_COLS,
                          c->col_hi + SPHHIP_HALO_COLS, l ? l + 1 : nullptr, l ? cap : 0, l ? (int*)l : c->counters,
                          r ? r + 1 : nullptr, r ? cap : 0, r ? (int*)r : c->counters + 1);

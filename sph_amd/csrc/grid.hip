@@ -1,5 +1,7 @@
-// grid.hip -- uniform-grid cell list for gfx950: cell hash, LDS-local LSD radix sort, monotone
-// cell start array, in-cell id ranking and the reorder of the SoA state into (key, id) order.
+// grid.hip -- uniform-grid cell list for gfx950: cell hash, sort by cell (default: one counting pass,
+// k_cell_count .. k_cell_scatter, or the whole build in one workgroup for small scenes, k_grid_small;
+// SPHHIP_GRID=radix: the LDS-local LSD radix sort, k_sort_*), monotone cell start array, in-cell id
+// ranking and the reorder of the SoA state into (key, id) order.
 //
 // There is no reference code for this phase: the reference only names `int* grid, int* cellStart,
 // int* cellEnd` as dead kernel parameters (SPH/sph.cuh:33-34,38; always nullptr, SPH/sph.cu:222-223).
@@ -248,8 +250,10 @@ __global__ __launch_bounds__(256) void k_sufmin_parts(int* __restrict__ part, in
 }
 
 __global__ __launch_bounds__(256) void k_sufmin_apply(int* __restrict__ a, int len, const int* __restrict__ part,
-                                                       const int* __restrict__ d_n) {
+                                                       const int* __restrict__ d_n, int* __restrict__ n_sorted) {
     const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
+    // the count at this sort: slots below it are in sorted order (k_split tells stale ghosts from appended records by it)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_sorted = n;
     __shared__ int buf[SCAN_CHUNK];
     __shared__ int wmin[4];
     int base = blockIdx.x * SCAN_CHUNK;
@@ -740,7 +744,8 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             }
             hipLaunchKernelGGL(k_sufmin_reduce, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp);
             hipLaunchKernelGGL(k_sufmin_parts, dim3(1), dim3(256), 0, st, c->scan_tmp, nparts);
-            hipLaunchKernelGGL(k_sufmin_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp, c->d_n);
+            hipLaunchKernelGGL(k_sufmin_apply, dim3(nparts), dim3(256), 0, st, c->cell_start, len, c->scan_tmp, c->d_n,
+                               c->counters + SPH_N_SORTED_SLOT);
             LAUNCH_CHECK();
         }
     }

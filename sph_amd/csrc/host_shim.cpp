@@ -57,9 +57,11 @@ bool download(std::vector<Particle>& v, int n) {
 }
 }  // namespace
 
+// Message of the most recent shim call's failure (empty if it succeeded): every public call clears it first.
 const char* hip_lastError() { return g_err.c_str(); }
 
 void hip_cleanupSimulation() {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     if (g_ctx) sphhip_destroy(g_ctx);
     g_ctx = nullptr;
     g_cap = 0;
@@ -67,6 +69,7 @@ void hip_cleanupSimulation() {
 }
 
 void hip_initSimulation(std::vector<Particle>& particles, int N) {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     particles.resize(N);
     // SPH/sph.cpp:136-152, same expression order in binary32
     int cols = static_cast<int>(std::ceil(std::sqrt((double)N)));
@@ -91,6 +94,7 @@ void hip_initSimulation(std::vector<Particle>& particles, int N) {
 
 void hip_buildNeighbors(std::vector<Particle>& particles, int N, std::vector<int>* keys, std::vector<int>* order,
                         std::vector<int>* cellStart, std::vector<int>* cellEnd) {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     if (!upload(particles, N)) return;
     int rc = sphhip_build_grid(g_ctx);
     if (rc) {
@@ -111,6 +115,7 @@ void hip_buildNeighbors(std::vector<Particle>& particles, int N, std::vector<int
 }
 
 void hip_computeDensityPressure(std::vector<Particle>& particles, int N) {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     if (!upload(particles, N)) return;
     int rc = sphhip_density(g_ctx);
     if (rc) {
@@ -121,6 +126,7 @@ void hip_computeDensityPressure(std::vector<Particle>& particles, int N) {
 }
 
 void hip_computeForces(std::vector<Particle>& particles, int N, float2 mousePos, float interactionStrength) {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     if (!upload(particles, N)) return;
     int rc = sphhip_forces(g_ctx, mousePos.x, mousePos.y, interactionStrength);
     if (rc) {
@@ -131,6 +137,7 @@ void hip_computeForces(std::vector<Particle>& particles, int N, float2 mousePos,
 }
 
 void hip_integrate(std::vector<Particle>& particles, int N) {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     if (!upload(particles, N)) return;
     int rc = sphhip_integrate(g_ctx);
     if (rc) {
@@ -142,6 +149,7 @@ void hip_integrate(std::vector<Particle>& particles, int N) {
 
 void hip_stepSimulationResident(std::vector<Particle>& particles, int N, float2 mousePos, float interactionStrength,
                                 int nsteps) {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     if (!upload(particles, N)) return;
     int rc = sphhip_step(g_ctx, mousePos.x, mousePos.y, interactionStrength, nsteps);
     if (rc) {
@@ -165,6 +173,7 @@ void write_vbo(const Particle* particles, int N, void* vbo) {  // updateVBO, SPH
 }  // namespace
 
 void hip_initSimulation(Particle* particles, int N, void* vbo) {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     if (!particles || N < 0) {
         g_err = "hip_initSimulation: bad argument";
         return;
@@ -184,6 +193,7 @@ void hip_initSimulation(Particle* particles, int N, void* vbo) {
 
 void hip_stepSimulation(Particle* particles, int N, int* grid, int* cellStart, int* cellEnd, void* vbo, float2 mousePos,
                         float interactionStrength) {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     if (!particles || N < 0) {
         g_err = "hip_stepSimulation: bad argument";
         return;
@@ -225,6 +235,7 @@ void hip_stepSimulation(Particle* particles, int N, int* grid, int* cellStart, i
 }
 
 float HIP_performance_test(int N) {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     std::vector<Particle> particles;
     hip_initSimulation(particles, N);
     if (!upload(particles, N)) return 0.0f;
@@ -248,6 +259,7 @@ float HIP_performance_test(int N) {
 }
 
 int HIP_main_headless(int N, int steps, const char* dump_path) {
+    g_err.clear();  // hip_lastError() describes the most recent call only
     std::vector<Particle> particles;
     hip_initSimulation(particles, N);
     hip_stepSimulationResident(particles, N, float2(0.0f, 0.0f), 0.0f, steps);

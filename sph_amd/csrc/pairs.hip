@@ -21,6 +21,33 @@
 #include "sphhip_internal.h"
 #include "exact_div.h"
 
+// Diagnostic build only (-DSPH_STAMPS, tools/stamps.py): every wave of k_force writes s_memtime stamps of its
+// tile phases into g_stamps (8 words per wave and tile-list entry).  Not compiled into the product library.
+#ifdef SPH_STAMPS
+constexpr int STAMP_TILES = 1 << 16;
+__device__ unsigned long long g_stamps[STAMP_TILES * 4 * 8];
+#define STAMP_PARAM , int stamp_slot
+#define STAMP_ARG , stamp_slot
+#define STAMP(k)                                                                                              \
+    do {                                                                                                      \
+        if (stamp_slot >= 0 && (tix & 63) == 0)                                                               \
+            g_stamps[((size_t)stamp_slot * 4 + (tix >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime();         \
+    } while (0)
+#define STAMP_VAL(k, v)                                                                                       \
+    do {                                                                                                      \
+        if (stamp_slot >= 0 && (tix & 63) == 0) g_stamps[((size_t)stamp_slot * 4 + (tix >> 6)) * 8 + (k)] = (v); \
+    } while (0)
+extern "C" int sphhip_debug_read_stamps(unsigned long long* out, int tiles) {
+    if (tiles > STAMP_TILES) tiles = STAMP_TILES;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)tiles * 32) == hipSuccess ? 0 : -2;
+}
+#else
+#define STAMP_PARAM
+#define STAMP_ARG
+#define STAMP(k) do { } while (0)
+#define STAMP_VAL(k, v) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Tile = `tile_cells` consecutive cells [cy0, cy1) of grid column `col`.  Its neighbour candidates
 // are the cells of rows [ylo, yhi) in columns col-1, col, col+1.  They are staged in LDS in
@@ -227,7 +254,11 @@ __device__ __forceinline__ void for_each_tile(const TileQueue& q, Body&& body) {
         __syncthreads();  // the previous tile is done with the LDS image
         int tix = threadIdx.x;
         asm volatile("" : "+v"(tix));
+#ifdef SPH_STAMPS
+        body(tile / q.tiles_per_col, tile % q.tiles_per_col, tix, t);
+#else
         body(tile / q.tiles_per_col, tile % q.tiles_per_col, tix);
+#endif
         t = t_next;
         tile = tile_next;
     }
@@ -404,7 +435,11 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
     int* s_off = reinterpret_cast<int*>(s_pos + cap);
     int* s_gs = s_off + PAIR_MAXC + 1;
     int* s_wave = s_gs + PAIR_MAXC;
+#ifdef SPH_STAMPS
+    for_each_tile(q, [&](int col, int trow, int tix, int) {
+#else
     for_each_tile(q, [&](int col, int trow, int tix) {
+#endif
         if (col < col_lo || col >= col_hi) return;  // (the list may cover the force pass's wider range)
         density_tile<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, col, trow, tile_cells, cap, sink,
                               s_pos, s_off, s_gs, s_wave, tix);
@@ -785,7 +820,8 @@ __device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __r
                                            float2* __restrict__ vel_o, const TileGeom& g, int cap, float mx, float my,
                                            float strength, int allow_fast, const uint32_t* __restrict__ nmask,
                                            int n_max, const DenseSink& sink, PairRec* s_rec, int* s_off, int* s_gs,
-                                           uint8_t* s_q, int tix) {
+                                           uint8_t* s_q, int tix STAMP_PARAM) {
+    STAMP(1);  // tile_setup done
     // the first batch of own particles is fetched now, so that the loads overlap the staging below
     OwnParticle own0;
     own0.load(g.own_lo + tix, g.own_lo + tix < g.own_hi, pos, vel, rho, prs, idv, skeys);
@@ -872,6 +908,8 @@ __device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __r
         fast = !__syncthreads_or(unsafe);
         by_mask = !__syncthreads_or(no_mask) && fast;
     }
+    STAMP(2);  // staged
+    STAMP_VAL(5, (unsigned long long)(g.own_hi - g.own_lo) | ((unsigned long long)g.total << 32));
 
     // All lanes of a wave stay in the loop together (wave-level votes below); lanes without a
     // particle, or with an invalid one, simply have an empty candidate range.
@@ -924,6 +962,7 @@ __device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __r
                 }
             }
         }
+        STAMP(3);  // pair loop done
         if (have) {
             if (valid) {
                 force_epilogue<FUSE>(c, fx, fy, pi, vi, dens_i, mx, my, strength);
@@ -933,6 +972,7 @@ __device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __r
             vel_o[s] = vi;
         }
     }
+    STAMP(4);  // epilogue done
 }
 
 template <bool FUSE, int THREADS>
@@ -944,8 +984,9 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
                                            int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my,
                                            float strength, int allow_fast, const uint32_t* __restrict__ nmask,
                                            int n_max, const DenseSink& sink, PairRec* s_rec, int* s_off, int* s_gs,
-                                           int* s_wave, uint8_t* s_q, int tix) {
+                                           int* s_wave, uint8_t* s_q, int tix STAMP_PARAM) {
     const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
+    STAMP(0);  // tile start
     // ghost column of a slab: pass the particles through (cheap test before any setup)
     if (col < own_lo_col || col >= own_hi_col) {
         int lo = cell_start[col * c.ny + cy0], hi = cell_start[col * c.ny + cy1];
@@ -961,7 +1002,7 @@ __device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __r
         asm volatile("" : "+v"(tix));  // see density_tile
         if (tile_setup_fit<THREADS>(c, cell_start, col, a, h, cap, g, s_off, s_gs, s_wave, tix))
             force_rows<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, pos_o, vel_o, g, cap, mx, my, strength, allow_fast,
-                                      nmask, n_max, sink, s_rec, s_off, s_gs, s_q, tix);
+                                      nmask, n_max, sink, s_rec, s_off, s_gs, s_q, tix STAMP_ARG);
         a += h;
         if (a < cy1) __syncthreads();  // the next sub-tile reuses the LDS image
     }
@@ -981,13 +1022,24 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
     int* s_gs = s_off + PAIR_MAXC + 1;
     int* s_wave = s_gs + PAIR_MAXC;
     uint8_t* s_q = reinterpret_cast<uint8_t*>(s_wave + 8);
+#ifdef SPH_STAMPS
+    for_each_tile(q, [&](int col, int trow, int tix, int t_list) {
+        const int stamp_slot = t_list < STAMP_TILES ? t_list : -1;
+        if (stamp_slot >= 0 && (tix & 63) == 0) {
+            g_stamps[((size_t)stamp_slot * 4 + (tix >> 6)) * 8 + 6] =
+                (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) |  // HW_REG_XCC_ID
+                ((unsigned long long)blockIdx.x << 32);
+            g_stamps[((size_t)stamp_slot * 4 + (tix >> 6)) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        }
+#else
     for_each_tile(q, [&](int col, int trow, int tix) {
+#endif
         // columns [col_lo, col_hi) without [skip_lo, skip_hi): a slab step runs the columns next to the slab
         // boundaries first and the interior in a second launch (sph_force_launch)
         if (col < col_lo || col >= col_hi || (col >= skip_lo && col < skip_hi)) return;
         force_tile<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, col, trow, tile_cells, cap,
                                   own_lo_col, own_hi_col, mx, my, strength, allow_fast, nmask, n_max, sink, s_rec, s_off,
-                                  s_gs, s_wave, s_q, tix);
+                                  s_gs, s_wave, s_q, tix STAMP_ARG);
     });
 }
 

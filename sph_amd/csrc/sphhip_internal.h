@@ -121,6 +121,7 @@ struct SphCtx {
     struct {
         bool pending = false, masks_ok = false;
         int il = 0, ih = 0;  // interior columns
+        int edge_l = 0, edge_r = 0;  // owned columns sphhip_step_begin finished on each side
         float mx = 0, my = 0, strength = 0;
     } split;
 

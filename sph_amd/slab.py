@@ -79,7 +79,7 @@ class HipSlabBackend:
         self.solver = Solver(params, n_max=n_max, device=device)
         self.drv = self.solver.drv
         # run the library on torch's current stream so that RCCL ops and kernels are ordered
-        self.solver.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.solver.follow_torch_stream(torch.cuda.current_stream(self.device))
         self.cap = int(halo_cap)
         mk = lambda: torch.zeros((self.cap + 1, 5), dtype=torch.int32, device=self.device)  # noqa: E731
         self.send_l, self.send_r, self.recv_l, self.recv_r = mk(), mk(), mk(), mk()

@@ -123,11 +123,27 @@ class Solver:
         _lib.check(self.L.sphhip_set_tuning(self.h, int(tile_cells), int(pair_cap)))
 
     def set_stream(self, stream_ptr):
-        """Run on a caller-owned HIP stream; 0 / None selects the device's default (null) stream."""
-        if not stream_ptr:
-            _lib.check(self.L.sphhip_use_default_stream(self.h))
+        """Run on a caller-owned HIP stream (its handle as an int).  None selects the context's own stream, exactly
+        as sphhip_set_stream(ctx, NULL) does.  The handle 0 is HIP's null stream, which the C call cannot express
+        through its argument: it is refused here, use use_default_stream()."""
+        if stream_ptr is None:
+            _lib.check(self.L.sphhip_set_stream(self.h, ctypes.c_void_p(None)))
+        elif int(stream_ptr) == 0:
+            raise ValueError("stream handle 0 is the null stream: call use_default_stream() (None = the context's own stream)")
         else:
-            _lib.check(self.L.sphhip_set_stream(self.h, ctypes.c_void_p(stream_ptr)))
+            _lib.check(self.L.sphhip_set_stream(self.h, ctypes.c_void_p(int(stream_ptr))))
+
+    def use_default_stream(self):
+        """Run on the device's default (null) stream (sphhip_use_default_stream)."""
+        _lib.check(self.L.sphhip_use_default_stream(self.h))
+
+    def follow_torch_stream(self, torch_stream):
+        """Run on a torch.cuda stream (torch's default stream is HIP's null stream)."""
+        h = int(torch_stream.cuda_stream)
+        if h == 0:
+            self.use_default_stream()
+        else:
+            self.set_stream(h)
 
     def set_profiling(self, on):
         _lib.check(self.L.sphhip_set_profiling(self.h, 1 if on else 0))

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Phase timing inside k_force from the -DSPH_STAMPS diagnostic build (tools/build_variant.sh stamps "-DSPH_STAMPS"):
+   SPHHIP_LIB=$PWD/variants/stamps/libsphhip.so python tools/stamps.py [cols] [steps]
+Every wave stamps s_memtime at: 0 tile start, 1 tile_setup done, 2 candidates staged, 3 pair loop done, 4 epilogue
+done.  Prints the distribution of the phase lengths (shader cycles) and the timeline of the launch."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sph_amd import lib as _lib, scenes  # noqa: E402
+from sph_amd.solver import Solver  # noqa: E402
+
+cols = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+params, a = scenes.dam_break(cols)
+L = _lib.load()
+L.sphhip_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+with Solver(params, n_max=len(a)) as s:
+    s.upload(a)
+    s.stepSimulation(nsteps=steps)
+    s.synchronize()
+    tiles = 1 << 16
+    buf = np.zeros((tiles, 4, 8), np.uint64)
+    assert L.sphhip_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), tiles) == 0
+used = buf[:, 0, 0] != 0
+b = buf[used].astype(np.int64)
+print("tiles stamped:", used.sum())
+own = b[:, 0, 5] & 0xFFFFFFFF
+tot = b[:, 0, 5] >> 32
+print("own particles per tile: mean %.1f max %d; candidates: mean %.1f max %d" % (own.mean(), own.max(), tot.mean(), tot.max()))
+names = ["setup", "stage", "loop", "epilogue", "whole"]
+for w in range(4):
+    t = b[:, w, :5]
+    ok = (t[:, 0] != 0) & (t[:, 4] != 0)
+    d = np.stack([t[ok, 1] - t[ok, 0], t[ok, 2] - t[ok, 1], t[ok, 3] - t[ok, 2], t[ok, 4] - t[ok, 3], t[ok, 4] - t[ok, 0]], 1)
+    print("wave %d (%d tiles):" % (w, ok.sum()), "  ".join("%s p50 %d p90 %d mean %.0f" % (n, np.percentile(d[:, i], 50), np.percentile(d[:, i], 90), d[:, i].mean()) for i, n in enumerate(names)))
+# timeline in real time (100 MHz ticks) of tile starts; whole-tile length in shader cycles
+rt = b[:, 0, 7]
+rt0 = rt.min()
+start_us = (rt - rt0) / 100.0
+whole = (b[:, :3, 4].max(1) - b[:, 0, 0])
+print("launch span by tile starts: %.1f us; last tile start at %.1f us" % (start_us.max(), start_us.max()))
+hist, edges = np.histogram(start_us, bins=12)
+print("tile starts per %.1f-us bin:" % (edges[1] - edges[0]), hist.tolist())
+xcc = b[:, 0, 6] & 0xF
+print("tiles per XCC:", np.bincount(xcc, minlength=8).tolist())
+# shader clock estimate: cycles of the whole tile vs real time between this tile's start and the next stamp is not
+# available per tile; use the ratio over the launch
+cyc_span = b[:, :3, 4].max() - b[:, 0, 0].min()
+print("launch span in shader cycles (s_memtime): %d" % cyc_span)
+print("mean tile length %.0f cycles, p90 %.0f" % (whole.mean(), np.percentile(whole, 90)))
