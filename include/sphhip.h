@@ -154,6 +154,22 @@ int sphhip_integrate(SphCtx* ctx);
  * grid, density, then forces + velocity update + integrate + wall clamp fused in one kernel.
  * Replaces the 3-kernel loop of CUDA_performance_test (SPH/sph.cu:254-258). */
 int sphhip_step(SphCtx* ctx, float mouse_x, float mouse_y, float strength, int nsteps);
+/* NO COUNTERPART IN THE REFERENCE.  The same steps as sphhip_step for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): no context, no hipMalloc /
+ * hipFree / hipHostMalloc / stream or event creation inside.  The caller passes the input and the output, both DEVICE
+ * arrays of n 28-byte Particle records in the reference's index order (they may be the same array); every working
+ * buffer (sorted SoA state, cell tables, masks, tile list, counters) lives in a static device array of the library
+ * (16 MiB per GPU the library runs on, held until the process ends).  Limits: n <= SPHHIP_STATIC_MAX_N and a grid
+ * of at most SPHHIP_STATIC_MAX_CELLS cells (SphDerived nx * ny), SPHHIP_ECAPACITY beyond.  Enqueues on `hip_stream`
+ * (hipStream_t as void*; NULL = the null stream) of HIP device `device` and returns without synchronising; the
+ * output is complete when the stream reaches the end of the call's work.  All calls on one GPU share that GPU's
+ * array, which keeps the last call's contents (the call clears what must start at zero): calls that overlap on one
+ * GPU -- two streams, two host threads -- race.  Results equal sphhip_upload + sphhip_step + sphhip_download bit for
+ * bit. */
+#define SPHHIP_STATIC_MAX_N 65536
+#define SPHHIP_STATIC_MAX_CELLS 65536
+int sphhip_step_static(const SphParams* p, int device, const void* d_aos_in, void* d_aos_out, int n, float mouse_x,
+                       float mouse_y, float strength, int nsteps, void* hip_stream);
 /* One step in two halves, for a slab driver that overlaps the halo exchange with the step (replaces the
  * Allgather-then-compute order of mpi_computeStep, SPH/MPI_sph.cpp:135-243, where every rank waits for the
  * full state before it computes).  sphhip_step_begin: grid, density, and the force + integrate pass of the

@@ -162,20 +162,11 @@ static void free_all(SphCtx* c) {
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 }
 
-extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx** out) {
-    if (!p || !out) return fail(SPHHIP_EINVAL, "sphhip_create: null argument");
-    if (n_max < 1 || n_max > (1 << 30)) return fail(SPHHIP_EINVAL, "sphhip_create: n_max out of range");
-    SphDerived d;
-    int rc = sphhip_derive(p, &d);
-    if (rc) return rc;
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(SPHHIP_EINVAL, "sphhip_create: no such HIP device");
-    HIP_TRY(hipSetDevice(device));
-    SphCtx* c = new SphCtx();
-    c->params = *p;
+// Everything of a context that is not device memory: constants, geometry, tuning switches (environment).
+static void ctx_configure(SphCtx* c, const SphParams& p, const SphDerived& d, int n_max, int device) {
+    c->params = p;
     c->drv = d;
-    fill_dev_consts(*p, d, c->dc);
+    fill_dev_consts(p, d, c->dc);
     c->device = device;
     c->n_max = n_max;
     c->ncell = d.nx * d.ny;
@@ -191,10 +182,10 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     {   // exact_div.h needs every numerator of the pair force inside its safe range
         // inside [SPH_SAFE_LO, SPH_SAFE_HI] of exact_div.h with margin
         auto safe = [](float x) { x = std::fabs(x); return x >= 4e-12f && x <= 2.5e11f; };
-        float t = p->h;  // term = h - r_len <= h
-        // (p->h >= 2^-5: k_force's clamp of tiny pair distances relies on h - 2^-30 == h, see force_terms)
-        c->fast_div = p->h >= 0.03125f && safe(d.spiky * t * t) && safe(d.visc_mass * d.visc_lap * t) && safe(p->h) && safe(p->stiffness) &&
-                      safe(p->rest_density) && safe(d.spiky * 1e-8f * 1e-8f) && safe(d.visc_mass * d.visc_lap * 1e-8f);
+        float t = p.h;  // term = h - r_len <= h
+        // (p.h >= 2^-5: k_force's clamp of tiny pair distances relies on h - 2^-30 == h, see force_terms)
+        c->fast_div = p.h >= 0.03125f && safe(d.spiky * t * t) && safe(d.visc_mass * d.visc_lap * t) && safe(p.h) && safe(p.stiffness) &&
+                      safe(p.rest_density) && safe(d.spiky * 1e-8f * 1e-8f) && safe(d.visc_mass * d.visc_lap * 1e-8f);
         if (const char* e = getenv("SPHHIP_FAST_DIV")) c->fast_div = c->fast_div && atoi(e) != 0;
     }
     if (const char* e = getenv("SPHHIP_USE_MASKS")) c->use_masks = atoi(e) != 0;
@@ -211,40 +202,73 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
         int v = atoi(e);
         if (v >= 64 && v <= 4608) c->pair_cap = v;
     }
+}
+
+// The device buffers of a context, one call of f(slot, bytes, zero) each: sphhip_create gives every buffer a
+// hipMalloc of its own, sphhip_step_static carves them out of the library's static scratch array.
+// zero: the buffer must start as zeros (index arrays start defined: a stale entry must never be an out-of-range
+// index; counters and cell tables start at 0).
+template <class F>
+static void ctx_buffers(SphCtx* c, bool with_staging, F&& f) {
+    const size_t n = (size_t)c->n_max;
+    const int nblocks = (c->n_max + SORT_TILE - 1) / SORT_TILE;
+    for (float2** p : {&c->pos, &c->vel, &c->pos2, &c->vel2}) f((void**)p, sizeof(float2) * n, false);
+    for (float** p : {&c->rho, &c->prs, &c->rho2, &c->prs2}) f((void**)p, sizeof(float) * n, false);
+    f((void**)&c->ncount, sizeof(int) * n, false);
+    f((void**)&c->nmask, sizeof(uint32_t) * n * 8, false);
+    for (uint32_t** p : {&c->keys, &c->keys2, &c->perm, &c->perm2, &c->ids_sorted, &c->idv, &c->idv2})
+        f((void**)p, sizeof(uint32_t) * n, true);
+    // two cell tables, each followed by the partial sums of its scan (see grid.hip)
+    const size_t words = (size_t)c->ncell + 1 + ((size_t)c->ncell + 1 + 2047) / 2048 + 8;
+    for (int b = 0; b < 2; b++) f((void**)&c->cell_buf[b], sizeof(int) * words, true);
+    f((void**)&c->block_hist, sizeof(int) * (size_t)SORT_RADIX * nblocks, false);
+    f((void**)&c->digit_total, sizeof(int) * 2 * SORT_RADIX, false);
+    f((void**)&c->scan_tmp, sizeof(int) * ((size_t)(c->ncell + 1 + 2047) / 2048 + 1), false);
+    f((void**)&c->counters, sizeof(int) * 64, true);
+    c->tile_list_cap = c->ncell + c->ncell / 64 + 64;
+    f((void**)&c->tile_list, sizeof(int) * (size_t)c->tile_list_cap, true);
+    // a dense sub-tile holds more candidates than the smallest LDS budget (64 records, 9 of them sentinels) and
+    // a particle is a candidate of at most 9 one-row sub-tiles; one entry per sub-tile and DENSE_THREADS own
+    // particles: 9 n / 55 + n / 256 < n / 4 entries cover it
+    c->dense_cap = c->n_max / 4 + 64;
+    if (const char* e = getenv("SPHHIP_DENSE_CAP")) c->dense_cap = std::max(1, atoi(e));  // (tests: force an overflow)
+    f((void**)&c->dense_list, sizeof(int4) * (size_t)c->dense_cap, false);
+    if (with_staging) f(&c->staging, std::max<size_t>(n * SPHHIP_PARTICLE_BYTES, 64), false);
+}
+
+// Pointers into those buffers, and the state of a context that holds no particles yet.
+static void ctx_wire(SphCtx* c) {
+    c->cell_start = c->cell_buf[0];
+    c->cell_cur = 0;
+    c->cell_next_zeroed = true;
+    c->d_err = c->counters + 16;
+    c->n_ring = c->counters + 32;
+    c->n_slot = 0;
+    c->d_n = c->n_ring;
+}
+
+extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx** out) {
+    if (!p || !out) return fail(SPHHIP_EINVAL, "sphhip_create: null argument");
+    if (n_max < 1 || n_max > (1 << 30)) return fail(SPHHIP_EINVAL, "sphhip_create: n_max out of range");
+    SphDerived d;
+    int rc = sphhip_derive(p, &d);
+    if (rc) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(SPHHIP_EINVAL, "sphhip_create: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    SphCtx* c = new SphCtx();
+    ctx_configure(c, *p, d, n_max, device);
     const size_t n = (size_t)n_max;
-    const int nblocks = (n_max + SORT_TILE - 1) / SORT_TILE;
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    ok(dmalloc(&c->pos, n)); ok(dmalloc(&c->vel, n)); ok(dmalloc(&c->pos2, n)); ok(dmalloc(&c->vel2, n));
-    ok(dmalloc(&c->rho, n)); ok(dmalloc(&c->prs, n)); ok(dmalloc(&c->rho2, n)); ok(dmalloc(&c->prs2, n));
-    ok(dmalloc(&c->idv, n)); ok(dmalloc(&c->idv2, n)); ok(dmalloc(&c->ncount, n));
-    ok(dmalloc(&c->nmask, n * 8));
-    ok(dmalloc(&c->keys, n)); ok(dmalloc(&c->keys2, n)); ok(dmalloc(&c->perm, n)); ok(dmalloc(&c->perm2, n));
-    ok(dmalloc(&c->ids_sorted, n));
-    if (e == hipSuccess) {  // index arrays start defined: a stale entry must never be an out-of-range index
-        for (void* p : {(void*)c->keys, (void*)c->keys2, (void*)c->perm, (void*)c->perm2, (void*)c->ids_sorted, (void*)c->idv,
-                        (void*)c->idv2})
-            ok(hipMemset(p, 0, sizeof(uint32_t) * std::max<size_t>(n, 1)));
-    }
-    {   // two cell tables, each followed by the partial sums of its scan (see grid.hip)
-        const size_t words = (size_t)c->ncell + 1 + ((size_t)c->ncell + 1 + 2047) / 2048 + 8;
-        for (int b = 0; b < 2; b++) {
-            ok(dmalloc(&c->cell_buf[b], words));
-            if (e == hipSuccess) ok(hipMemset(c->cell_buf[b], 0, sizeof(int) * words));
-        }
-        c->cell_start = c->cell_buf[0];
-        c->cell_cur = 0;
-        c->cell_next_zeroed = true;
-    }
-    ok(dmalloc(&c->block_hist, (size_t)SORT_RADIX * nblocks));
-    ok(dmalloc(&c->digit_total, 2 * SORT_RADIX));
-    ok(dmalloc(&c->scan_tmp, (size_t)(c->ncell + 1 + 2047) / 2048 + 1));
-    ok(dmalloc(&c->counters, 64));
-    c->tile_list_cap = c->ncell + c->ncell / 64 + 64;
-    ok(dmalloc(&c->tile_list, (size_t)c->tile_list_cap));
-    if (e == hipSuccess) ok(hipMemset(c->tile_list, 0, sizeof(int) * (size_t)c->tile_list_cap));
+    ctx_buffers(c, true, [&](void** slot, size_t bytes, bool zero) {
+        ok(hipMalloc(slot, std::max<size_t>(bytes, 4)));
+        if (e == hipSuccess && zero) ok(hipMemset(*slot, 0, std::max<size_t>(bytes, 4)));
+    });
+    ctx_wire(c);
     ok(hipHostMalloc((void**)&c->h_host_tiles, 2 * sizeof(int), hipHostMallocMapped));
     if (e == hipSuccess) {
         c->h_host_tiles[0] = -1;
@@ -252,22 +276,11 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
         ok(hipHostGetDevicePointer((void**)&c->d_host_tiles, c->h_host_tiles, 0));
     }
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->num_cus = v; }
-    // a dense sub-tile holds more candidates than the smallest LDS budget (64 records, 9 of them sentinels) and
-    // a particle is a candidate of at most 9 one-row sub-tiles; one entry per sub-tile and DENSE_THREADS own
-    // particles: 9 n / 55 + n / 256 < n / 4 entries cover it
-    c->dense_cap = n_max / 4 + 64;
-    if (const char* e = getenv("SPHHIP_DENSE_CAP")) c->dense_cap = std::max(1, atoi(e));  // (tests: force an overflow)
-    ok(hipMalloc((void**)&c->dense_list, sizeof(int4) * (size_t)c->dense_cap));
     ok(hipHostMalloc((void**)&c->h_dense, 2 * sizeof(int), hipHostMallocMapped));
     if (e == hipSuccess) {
         c->h_dense[0] = c->h_dense[1] = -1;
         ok(hipHostGetDevicePointer((void**)&c->d_dense, c->h_dense, 0));
     }
-    if (e == hipSuccess) ok(hipMemset(c->counters, 0, sizeof(int) * 64));
-    c->d_err = c->counters + 16;
-    c->n_ring = c->counters + 32;
-    c->d_n = c->n_ring;
-    ok(hipMalloc(&c->staging, std::max<size_t>(n * SPHHIP_PARTICLE_BYTES, 64)));
     if (e == hipSuccess && getenv("SPHHIP_POISON")) {
         // debugging aid: data buffers start as 0xFF bytes (NaN floats, huge integers), so that a read of something
         // never written shows up in the results instead of depending on what the allocator recycled.  The value
@@ -1200,5 +1213,114 @@ extern "C" int sphhip_reset_phase_times(SphCtx* c) {
         c->timer.ms[ph] = 0;
         c->timer.launches[ph] = 0;
     }
+    return SPHHIP_OK;
+}
+
+// ---- the entry point that allocates nothing (include/sphhip.h: sphhip_step_static) --------------
+// Every buffer sphhip_create would allocate for a context of SPHHIP_STATIC_MAX_N particles on a grid of
+// SPHHIP_STATIC_MAX_CELLS cells is carved out of one file-scope device array.  Every GPU the library runs on
+// holds its own copy of that array (at its own address) until the process ends; calls on one GPU share it and
+// therefore must not overlap.
+constexpr size_t STATIC_SCRATCH_BYTES = 16u << 20;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+namespace {
+struct StaticSlot {
+    unsigned char* ptr = nullptr;  // device address of `scratch` on this GPU (hipGetSymbolAddress), never the symbol itself
+    SphCtx ctx;
+    int host_tiles[2] = {-1, 0};   // stand-ins for the mapped host words of a normal context: always "unknown"
+    int host_dense[2] = {-1, -1};
+};
+constexpr int STATIC_MAX_DEVICES = 64;
+StaticSlot* g_static[STATIC_MAX_DEVICES] = {nullptr};
+
+// ids are 0..n-1 here: record k of the output is the particle with id k (the caller's index order)
+__global__ __launch_bounds__(256) void k_pack_aos_by_id(uint32_t* __restrict__ aos, const int* __restrict__ d_n,
+                                                         const float2* __restrict__ pos, const float2* __restrict__ vel,
+                                                         const float* __restrict__ rho, const float* __restrict__ prs,
+                                                         const uint32_t* __restrict__ idv) {
+    const int n = *d_n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = idv[i];
+    const uint32_t id = w & SPH_ID_MASK;
+    if (id >= (uint32_t)n) return;  // (cannot happen: ids are assigned by this call)
+    uint32_t* r = aos + (size_t)id * 7;
+    const float2 p = pos[i], v = vel[i];
+    r[0] = __float_as_uint(p.x);
+    r[1] = __float_as_uint(p.y);
+    r[2] = __float_as_uint(v.x);
+    r[3] = __float_as_uint(v.y);
+    r[4] = __float_as_uint(rho[i]);
+    r[5] = __float_as_uint(prs[i]);
+    r[6] = (w & SPH_INVALID_BIT) ? 0u : 1u;
+}
+}  // namespace
+
+extern "C" int sphhip_step_static(const SphParams* p, int device, const void* d_aos_in, void* d_aos_out, int n, float mx,
+                                  float my, float strength, int nsteps, void* hip_stream) {
+    if (!p || (n > 0 && (!d_aos_in || !d_aos_out))) return fail(SPHHIP_EINVAL, "sphhip_step_static: null argument");
+    if (n < 0 || nsteps < 0) return fail(SPHHIP_EINVAL, "sphhip_step_static: negative n / nsteps");
+    if (n > SPHHIP_STATIC_MAX_N)
+        return fail(SPHHIP_ECAPACITY, "sphhip_step_static: n exceeds SPHHIP_STATIC_MAX_N (use a context: sphhip_create / sphhip_step)");
+    SphDerived d;
+    int rc = sphhip_derive(p, &d);
+    if (rc) return rc;
+    if ((long long)d.nx * d.ny > SPHHIP_STATIC_MAX_CELLS)
+        return fail(SPHHIP_ECAPACITY, "sphhip_step_static: the grid has more than SPHHIP_STATIC_MAX_CELLS cells (use a context)");
+    if (n == 0) return SPHHIP_OK;
+    if (device < 0 || device >= STATIC_MAX_DEVICES) return fail(SPHHIP_EINVAL, "sphhip_step_static: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    // set-up, once per device, with that device current: the address of this GPU's copy of the array
+    if (!g_static[device]) {
+        unsigned char* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(SPHHIP_EHIP, "sphhip_step_static: hipGetSymbolAddress returned a null address");
+        static StaticSlot slots[STATIC_MAX_DEVICES];  // host memory of the library image: nothing is allocated
+        slots[device].ptr = ptr;
+        g_static[device] = &slots[device];
+    }
+    StaticSlot& sl = *g_static[device];
+    SphCtx* c = &sl.ctx;
+    *c = SphCtx();
+    // the buffers are sized for the maxima, whatever this call's n and grid are (one layout, checked once)
+    ctx_configure(c, *p, d, SPHHIP_STATIC_MAX_N, device);
+    const int ncell = c->ncell;
+    c->ncell = SPHHIP_STATIC_MAX_CELLS;
+    size_t off = 0;
+    ctx_buffers(c, false, [&](void** slot, size_t bytes, bool) {
+        *slot = sl.ptr + off;
+        off += (std::max<size_t>(bytes, 4) + 255) & ~(size_t)255;
+    });
+    c->ncell = ncell;
+    // two words for what a normal context keeps in mapped host memory (the kernels write there, this path never reads it)
+    c->d_host_tiles = (int*)(sl.ptr + off);
+    c->d_dense = (int*)(sl.ptr + off + 256);
+    off += 512;
+    if (off > STATIC_SCRATCH_BYTES) return fail(SPHHIP_ECAPACITY, "sphhip_step_static: internal layout exceeds the static scratch array");
+    ctx_wire(c);
+    sl.host_tiles[0] = -1;
+    sl.host_tiles[1] = 0;
+    sl.host_dense[0] = sl.host_dense[1] = -1;
+    c->h_host_tiles = sl.host_tiles;
+    c->h_dense = sl.host_dense;
+    c->own_stream = nullptr;
+    c->stream = (hipStream_t)hip_stream;
+    c->graph_off = true;      // (instantiating a graph allocates)
+    c->profiling = false;     // (so does creating events)
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->num_cus = v; }
+    // The array keeps the last call's contents: everything that must start at zero (counters, cell tables, index
+    // arrays, tile list) is cleared -- simply all of the part in use.
+    HIP_TRY(hipMemsetAsync(sl.ptr, 0, off, c->stream));
+    hipLaunchKernelGGL(k_unpack_aos, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)d_aos_in, n, 0u, c->pos,
+                       c->vel, c->rho, c->prs, c->idv);
+    LAUNCH_CHECK();
+    if ((rc = sph_set_n_host(c, n))) return rc;
+    c->have_state = true;
+    for (int s = 0; s < nsteps; s++)
+        if ((rc = step_once(c, mx, my, strength))) return rc;
+    hipLaunchKernelGGL(k_pack_aos_by_id, dim3((n + 255) / 256), dim3(256), 0, c->stream, (uint32_t*)d_aos_out, c->d_n, c->pos,
+                       c->vel, c->rho, c->prs, c->idv);
+    LAUNCH_CHECK();
     return SPHHIP_OK;
 }

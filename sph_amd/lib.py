@@ -3,6 +3,7 @@ library is missing this module raises at import of the symbol table, and every c
 a GPU."""
 import ctypes
 import os
+import sys
 
 from .params import SphDerived, SphParams
 
@@ -36,6 +37,7 @@ SIGNATURES = {
     "sphhip_forces": [_vp, _cf, _cf, _cf],
     "sphhip_integrate": [_vp],
     "sphhip_step": [_vp, _cf, _cf, _cf, _ci],
+    "sphhip_step_static": [ctypes.POINTER(SphParams), _ci, _vp, _vp, _ci, _cf, _cf, _cf, _ci, _vp],
     "sphhip_step_begin": [_vp, _cf, _cf, _cf, _ci, _ci],
     "sphhip_step_finish": [_vp],
     "sphhip_step_reference_order": [_vp, _cf, _cf, _cf, _ci],
@@ -76,6 +78,16 @@ def load():
             "sph_amd/libsphhip.so is missing: build it with `make -C sph_amd/csrc` "
             "(or __graft_entry__.build()). There is no CPU fallback."
         )
+    # One HIP runtime per process: torch wheels bundle their own libamdhip64 / libhsa-runtime64.  If libsphhip.so is
+    # loaded first it brings in /opt/rocm's copies, torch later adds its own, and whichever runtime initialises second
+    # finds no device (hipErrorNoDevice).  Loaded after torch, libsphhip.so binds to the runtime torch already mapped.
+    # So when torch is installed it is imported first (SPHHIP_NO_TORCH_PRELOAD=1 skips this: processes that never
+    # touch torch).
+    if "torch" not in sys.modules and os.environ.get("SPHHIP_NO_TORCH_PRELOAD") != "1":
+        import importlib.util
+
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
