@@ -225,8 +225,9 @@ static void ctx_buffers(SphCtx* c, bool with_staging, F&& f) {
     f((void**)&c->digit_total, sizeof(int) * 2 * SORT_RADIX, false);
     f((void**)&c->scan_tmp, sizeof(int) * ((size_t)(c->ncell + 1 + 2047) / 2048 + 1), false);
     f((void**)&c->counters, sizeof(int) * 64, true);
-    c->tile_list_cap = c->ncell + c->ncell / 64 + 64;
-    f((void**)&c->tile_list, sizeof(int) * (size_t)c->tile_list_cap, true);
+    // every entry of the work list holds at least one particle and at least one cell row
+    c->tile_list_cap = (int)std::min<long long>((long long)c->ncell, (long long)c->n_max) + 64;
+    f((void**)&c->tile_list, sizeof(TileDesc) * (size_t)c->tile_list_cap, true);
     // a dense sub-tile holds more candidates than the smallest LDS budget (64 records, 9 of them sentinels) and
     // a particle is a candidate of at most 9 one-row sub-tiles; one entry per sub-tile and DENSE_THREADS own
     // particles: 9 n / 55 + n / 256 < n / 4 entries cover it

@@ -315,21 +315,20 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
                                                        const uint32_t* __restrict__ idv, float2* __restrict__ pos_o,
                                                        float2* __restrict__ vel_o, float* __restrict__ rho_o,
                                                        float* __restrict__ prs_o, uint32_t* __restrict__ idv_o,
-                                                       int reorder_blocks, TileListArgs tl, int ny,
-                                                       int* __restrict__ zero_buf, int zero_words,
+                                                       int head_blocks, int* __restrict__ zero_buf, int zero_words,
                                                        int* __restrict__ zero_buf2, int zero_words2, int ncell) {
-    if ((int)blockIdx.x >= reorder_blocks) {
-        // tail workgroups: list the non-empty tiles of the pair kernels for this grid, and zero the idle
-        // cell table for the next build -- two small launches saved per step
-        const int i = ((int)blockIdx.x - reorder_blocks) * (int)blockDim.x + (int)threadIdx.x;
-        sph_tile_list_thread(i, cell_start, ny, tl.tile_cells, tl.tiles_per_col, tl.col0, tl.ncols, tl.list, tl.count);
-        const int stride = ((int)gridDim.x - reorder_blocks) * (int)blockDim.x;
+    if ((int)blockIdx.x < head_blocks) {
+        // head workgroups: zero the idle cell table for the next build -- a small launch saved per step.  (The work
+        // list of the pair kernels was built here too: its 60 registers per thread cost the latency-bound reorder
+        // part half its occupancy, 33 instead of 17 us -- it is a kernel of its own now, k_tile_list_build.)
+        const int i = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x;
+        const int stride = head_blocks * (int)blockDim.x;
         for (int k = i; k < zero_words; k += stride) zero_buf[k] = 0;
         for (int k = i; k < zero_words2; k += stride) zero_buf2[k] = 0;
         return;
     }
     const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    int s = ((int)blockIdx.x - head_blocks) * blockDim.x + threadIdx.x;
     if (s >= n) return;
     uint32_t k = skeys[s];
     if (k >= (uint32_t)ncell) return;  // (never for a slot below the count; a stale key must not become an address)
@@ -605,9 +604,16 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_grid_small(
     }
     __syncthreads();  // the cell table is complete (and visible to this workgroup)
     for (int i0 = 0; i0 < tl.nthreads; i0 += SMALL_THREADS)
-        sph_tile_list_thread(i0 + tid, cell_start, c.ny, tl.tile_cells, tl.tiles_per_col, tl.col0, tl.ncols, tl.list, tl.count);
+        sph_tile_list_thread(i0 + tid, cell_start, c.nx, c.ny, tl, err);
     for (int k = tid; k < zero_words; k += SMALL_THREADS) zero_buf[k] = 0;
     for (int k = tid; k < zero_words2; k += SMALL_THREADS) zero_buf2[k] = 0;
+}
+
+// The work list of the pair kernels for the grid just built (sphhip_internal.h: sph_tile_list_thread).  Needs only
+// the finished cell table, so it runs right after the scan.
+__global__ __launch_bounds__(256) void k_tile_list_build(const int* __restrict__ cell_start, int nx, int ny, TileListArgs tl,
+                                                          int* __restrict__ err) {
+    sph_tile_list_thread((int)(blockIdx.x * blockDim.x + threadIdx.x), cell_start, nx, ny, tl, err);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -689,6 +695,14 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
                                c->counters + SPH_TILE_COUNT_SLOT, c->counters + SPH_N_SORTED_SLOT,
                                count_update ? sph_n_slot_next(c) : (int*)nullptr);
             LAUNCH_CHECK();
+            if (n > 0) {  // (k_scan_apply has zeroed the list's counter)
+                TileListArgs tl = {};
+                int lo = 0, hi = 0;
+                sph_tile_list_args(c, tl, lo, hi);
+                hipLaunchKernelGGL(k_tile_list_build, dim3((tl.nthreads + 255) / 256), dim3(256), 0, st, c->cell_start, c->dc.nx,
+                                   c->dc.ny, tl, c->d_err);
+                LAUNCH_CHECK();
+            }
         }
         if (n > 0 && !fused) {
             PhaseScope ps(c, SPHHIP_PH_SORT);
@@ -753,34 +767,31 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     if (n > 0) {
         PhaseScope ps(c, SPHHIP_PH_REORDER);
         const int nb = (n + 255) / 256;
-        // tail workgroups (counting path only): tile list of the pair kernels + zeroing of the idle cell table
-        TileListArgs tl = {};
-        int tail = 0, lo = 0, hi = 0;
+        // head workgroups (counting path only): zeroing of the idle cell table
+        int head = 0, lo = 0, hi = 0;
         if (c->grid_counting) {
-            sph_tile_list_args(c, tl, lo, hi);
-            tail = (tl.nthreads + 255) / 256;
+            TileListArgs tl = {};
+            sph_tile_list_args(c, tl, lo, hi);  // (lo, hi: the column range of the list built above)
+            head = std::min(64, (r_len + 2047) / 2048 + 1);
         }
         int* zero_buf = c->cell_buf[1 - c->cell_cur];
         if (fused) {
             // (k_grid_small has reordered, listed the tiles and zeroed the idle table)
         } else if (carry_density)
-            hipLaunchKernelGGL(k_rank_reorder<true>, dim3(nb + tail), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
+            hipLaunchKernelGGL(k_rank_reorder<true>, dim3(nb + head), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
                                c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
-                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf + r_first, r_len, zero_buf + len, r_parts, ncell);
+                               c->prs2, c->idv2, head, zero_buf + r_first, r_len, zero_buf + len, r_parts, ncell);
         else
-            hipLaunchKernelGGL(k_rank_reorder<false>, dim3(nb + tail), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
+            hipLaunchKernelGGL(k_rank_reorder<false>, dim3(nb + head), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
                                c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
-                               c->prs2, c->idv2, nb, tl, c->dc.ny, zero_buf + r_first, r_len, zero_buf + len, r_parts, ncell);
+                               c->prs2, c->idv2, head, zero_buf + r_first, r_len, zero_buf + len, r_parts, ncell);
         LAUNCH_CHECK();
-        if (tail > 0 && range_moved) {  // the tail zeroed only the new range of the old table
+        if (head > 0 && range_moved) {  // the head zeroed only the new range of the old table
             HIP_TRY(hipMemsetAsync(zero_buf, 0, sizeof(int) * (size_t)table_words, st));
         }
-        if (tail > 0) {
+        if (head > 0) {
             c->cell_next_zeroed = true;
-            c->tiles_valid = true;
-            c->tiles_cells = c->tile_cells;
-            c->tiles_lo = lo;
-            c->tiles_hi = hi;
+            sph_tiles_mark(c, lo, hi);
         }
         std::swap(c->pos, c->pos2);
         std::swap(c->vel, c->vel2);

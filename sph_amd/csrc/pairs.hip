@@ -74,9 +74,9 @@ constexpr int FORCE_QCAP = FORCE_Q + FORCE_SCAN_UNROLL + FORCE_HEAVY_UNROLL;  //
 // After the three cells of every candidate row the LDS image holds PAIR_ROW_PAD sentinel records at
 // +inf: a lane may read up to PAIR_ROW_PAD records past the end of its range without a bounds test
 // (r2 = +inf fails the distance test); the sentinels inside its range fail the same way.
-constexpr int PAIR_ROW_PAD = 3;
-constexpr int PAIR_STAGE_BATCH = 3;  // staging passes whose global loads are issued together (3 x 16 cells >= a 12-cell tile's 42)
-constexpr int FORCE_MAX_RANGE = 256;  // longest 3x3 stencil range (LDS records) the byte queue can index
+// (PAIR_ROW_PAD, and FORCE_MAX_RANGE -- the longest 3x3 stencil range the masks / the byte queue can index -- are in
+// sphhip_internal.h: the tile list builder needs them)
+constexpr int PAIR_STAGE_BATCH = 4;  // candidates per thread whose global loads are issued up front (4 x 256 >= the default LDS budget)
 constexpr int PAIR_MASK_WORDS = FORCE_MAX_RANGE / 32;  // in-range bit masks handed from k_density to k_force
 static_assert(FORCE_SCAN_UNROLL - 1 <= PAIR_ROW_PAD, "scan unroll reads past the range end");
 
@@ -166,22 +166,6 @@ __device__ __forceinline__ bool tile_setup(const DevConsts& c, const int* __rest
     return g.own_lo != g.own_hi;
 }
 
-// Sets up rows [a, a + h) of a tile, halving h until the candidates fit the LDS budget (or h == 1): a
-// tile in a compressed region is processed as a few shorter sub-tiles through the LDS path instead of
-// falling back to global memory as a whole.  Uniform over the workgroup; k_density and k_force take the
-// same decisions (same table, same budget), so the masks of one describe the LDS image of the other.
-template <int THREADS>
-__device__ __forceinline__ bool tile_setup_fit(const DevConsts& c, const int* __restrict__ cell_start, int col, int a,
-                                               int& h, int cap, TileGeom& g, int* s_off, int* s_gs, int* s_wave,
-                                               int tix) {
-    for (;;) {
-        const bool nonempty = tile_setup<THREADS>(c, cell_start, col, a, a + h, g, s_off, s_gs, s_wave, tix);
-        if (g.total <= cap || h == 1) return nonempty;
-        h = (h + 1) >> 1;
-        __syncthreads();  // everyone is done with this attempt's tables
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // density + pressure + neighbour count.   Algorithmic HBM bytes / particle: R pos 8, W rho 4 + P 4
 // (+ 4 for the neighbour count) = 16 (+4).
@@ -214,12 +198,11 @@ __device__ __forceinline__ void density_acc_mask(const DevConsts& c, float2 pi, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Work distribution of the pair kernels: a compacted list of the non-empty tiles.
-// ensure_tile_list (below) compacts the non-empty tiles of the launch range into `tile_list`
-// (tile id = col * tiles_per_col + trow, in band-major order: 4 adjacent columns, then rows) and
-// splits it into 8 contiguous chunks, one per XCD (workgroup b runs on XCD b % 8 under round-robin
-// dispatch): horizontally adjacent tiles -- which share two of their three candidate columns -- are
-// then served by the same XCD's L2.  A dam break fills an eighth of the grid: launching one workgroup
+// Work distribution of the pair kernels: a list of entries (sphhip_internal.h: TileDesc), one workgroup pass each,
+// built on the device right after the cell table (grid.hip: k_tile_list_build) in column-major order and split
+// into 8 contiguous chunks, one per XCD (workgroup b runs on XCD b % 8 under round-robin dispatch): an XCD works
+// on a block of adjacent columns, so horizontally adjacent tiles -- which share two of their three candidate
+// columns -- are served by the same L2.  A dam break fills an eighth of the grid: launching one workgroup
 // per tile of the whole grid spent a fifth of both pair kernels on empty workgroups.
 // The number of listed tiles is only known on the device.  The host sizes the grid from the count a
 // previous launch wrote into mapped host memory (one workgroup per tile, a little slack), or, while it
@@ -228,40 +211,111 @@ __device__ __forceinline__ void density_acc_mask(const DevConsts& c, float2 pi, 
 // in its latency-bound tile prologue at the same time.)
 // ---------------------------------------------------------------------------------------------
 struct TileQueue {
-    const int* list;   // compacted tile ids
-    const int* count;  // number of entries
-    int* host_count;   // mapped host memory: the count and the tiling it belongs to, for sizing later launches
-    int tiles_per_col, tile_cells;
+    const TileDesc* list;  // the work list (sphhip_internal.h: TileDesc)
+    const int* count;      // number of entries
+    int* host_count;       // mapped host memory: the count and the tiling it belongs to, for sizing later launches
+    int tile_cells;
 };
 
 // Workgroup b takes entry (b & 7) * gridDim/8 + (b >> 3), then strides by gridDim: chunk b & 7 of the
-// list goes to XCD b & 7.  The count and the first tile id are fetched together (wave-uniform loads);
-// the id of the next tile while the current one is processed.  `tix` is threadIdx.x behind an opaque
-// barrier: without it the compiler hoists ~20 VGPRs of thread-index arithmetic out of the (rarely
+// list goes to XCD b & 7.  The entry is read with wave-uniform (scalar) loads.  `tix` is threadIdx.x behind an
+// opaque barrier: without it the compiler hoists ~20 VGPRs of thread-index arithmetic out of the (rarely
 // repeated) loop and the force kernel drops from 4 to 3 workgroups per CU.
 template <class Body>
 __device__ __forceinline__ void for_each_tile(const TileQueue& q, Body&& body) {
     const int total = *q.count;
     int t = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    int tile = q.list[t];  // (the list is allocated for every t a launch can produce)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ((volatile int*)q.host_count)[0] = total;
         ((volatile int*)q.host_count)[1] = q.tile_cells;
     }
     while (t < total) {
-        const int t_next = t + (int)gridDim.x;
-        const int tile_next = t_next < total ? q.list[t_next] : 0;
-        __syncthreads();  // the previous tile is done with the LDS image
+        const TileDesc d = q.list[t];
+        __syncthreads();  // the previous entry is done with the LDS image
         int tix = threadIdx.x;
         asm volatile("" : "+v"(tix));
-#ifdef SPH_STAMPS
-        body(tile / q.tiles_per_col, tile % q.tiles_per_col, tix, t);
-#else
-        body(tile / q.tiles_per_col, tile % q.tiles_per_col, tix);
-#endif
-        t = t_next;
-        tile = tile_next;
+        body(d, tix, t);
+        t += (int)gridDim.x;
     }
+}
+
+// Geometry of a list entry (no memory access).
+__device__ __forceinline__ TileGeom entry_geom(const DevConsts& c, const TileDesc& d) {
+    TileGeom g;
+    g.col = d.col;
+    g.cy0 = d.cy0;
+    g.cy1 = d.cy1;
+    g.ylo = max(d.cy0 - 1, 0);
+    g.yhi = min(d.cy1 + 1, c.ny);
+    g.own_lo = d.own_lo;
+    g.own_hi = d.own_hi;
+    g.ncells = 3 * (g.yhi - g.ylo);
+    g.total = 0;
+    return g;
+}
+
+// The candidate-cell table of an entry, in two halves so that the global loads of the first half are in flight
+// together with everything else the prologue of a pair kernel loads:
+//   entry_cells_load   thread t < ncells fetches the slot range [g0, g1) of candidate cell t (row-major: t = 3 row + d)
+//   entry_cells_table  exclusive scan of the padded counts -> s_off[0..ncells], s_gs[0..ncells), g.total (one barrier
+//                      inside for entries of more than 64 candidate cells; the caller's barrier publishes the table)
+__device__ __forceinline__ void entry_cells_load(const DevConsts& c, const int* __restrict__ cell_start, const TileGeom& g,
+                                                 int tix, int& g0, int& g1) {
+    g0 = g1 = 0;
+    if (tix < g.ncells) {
+        const int row = tix / 3, dd = tix - 3 * row;
+        const int cc = g.col - 1 + dd;
+        if (cc >= 0 && cc < c.nx) {
+            const int key = cc * c.ny + g.ylo + row;
+            g0 = cell_start[key];
+            g1 = cell_start[key + 1];
+        }
+    }
+}
+
+template <int THREADS>
+__device__ __forceinline__ void entry_cells_table(TileGeom& g, int g0, int g1, int* s_off, int* s_gs, int* s_wave, int tix) {
+    const int lane = tix & 63, wave = tix >> 6;
+    const bool mine = tix < g.ncells;
+    const int padded = mine ? (g1 - g0) + ((tix % 3) == 2 ? PAIR_ROW_PAD : 0) : 0;
+    int incl = padded;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+        const int t = __shfl_up(incl, k, 64);
+        if (lane >= k) incl += t;
+    }
+    int before = 0;
+    if (g.ncells > 64) {  // (uniform; tiles of more than 19 rows)
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; w++) before += (w < wave) ? s_wave[w] : 0;
+    }
+    if (mine) {
+        s_off[tix] = before + incl - padded;
+        s_gs[tix] = g0;
+        if (tix == g.ncells - 1) s_off[g.ncells] = before + incl;
+    }
+}
+
+// Candidate i of an entry's concatenated candidate sequence (column col-1, then col, then col+1; ascending slot):
+// its global slot and its column 0..2.
+__device__ __forceinline__ int entry_cand_slot(const TileDesc& d, int i, int& dd) {
+    const int n0 = d.c_hi[0] - d.c_lo[0], n1 = d.c_hi[1] - d.c_lo[1];
+    dd = (i >= n0 ? 1 : 0) + (i >= n0 + n1 ? 1 : 0);
+    return i + (dd == 0 ? d.c_lo[0] : dd == 1 ? d.c_lo[1] - n0 : d.c_lo[2] - n0 - n1);
+}
+__device__ __forceinline__ int entry_cand_count(const TileDesc& d) {
+    return (d.c_hi[0] - d.c_lo[0]) + (d.c_hi[1] - d.c_lo[1]) + (d.c_hi[2] - d.c_lo[2]);
+}
+// LDS slot of the candidate at global slot `slot`, column dd, cell key `key` (clamped: a stale key must not become
+// an address outside the image).
+__device__ __forceinline__ int entry_cand_dst(const DevConsts& c, const TileGeom& g, const int* s_off, const int* s_gs,
+                                              int slot, int dd, uint32_t key, int cap) {
+    int cc = 3 * ((int)key - (g.col - 1 + dd) * c.ny - g.ylo) + dd;
+    cc = min(max(cc, 0), g.ncells - 1);
+    const int dst = s_off[cc] + (slot - s_gs[cc]);
+    return min(max(dst, 0), cap - 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -312,50 +366,60 @@ __device__ __forceinline__ bool dense_defer(const DenseSink& d, const TileGeom& 
     return d.defer != 0;
 }
 
+// One list entry of the density pass.  Prologue: every global load it needs -- candidate-cell table, own particles,
+// candidate positions and keys (contiguous slot ranges straight from the entry, PAIR_STAGE_BATCH per thread) -- is
+// issued before the first one is waited for: one memory round trip and two barriers, where walking from the cell
+// table to the particle data took three dependent round trips (stamps: 9 of 24 us per tile).
 template <int THREADS>
-__device__ __forceinline__ void density_rows(const DevConsts& c, const float2* __restrict__ pos,
-                                             const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
-                                             float* __restrict__ rho, float* __restrict__ prs,
-                                             int* __restrict__ ncount, uint32_t* __restrict__ nmask, int n_max,
-                                             const TileGeom& g, int cap, const DenseSink& sink, float2* s_pos,
-                                             int* s_off, int* s_gs, int tix) {
-    // the first batch of own particles is fetched now, so that the loads overlap the staging below
+__device__ __forceinline__ void density_entry(const DevConsts& c, const float2* __restrict__ pos,
+                                              const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
+                                              float* __restrict__ rho, float* __restrict__ prs,
+                                              int* __restrict__ ncount, uint32_t* __restrict__ nmask, int n_max,
+                                              const TileDesc& d, int cap, const DenseSink& sink, float2* s_pos,
+                                              int* s_off, int* s_gs, int* s_wave, int tix) {
+    TileGeom g = entry_geom(c, d);
+    const bool use_lds = (d.info & TILE_DENSE) == 0;
+    if (!use_lds && dense_defer(sink, g, tix)) return;
+    int g0, g1;
+    entry_cells_load(c, cell_start, g, tix, g0, g1);
     float2 pi0 = make_float2(0.0f, 0.0f);
     uint32_t key0 = 0;
     if (g.own_lo + tix < g.own_hi) {
         pi0 = pos[g.own_lo + tix];
         key0 = skeys[g.own_lo + tix];
     }
+    const int n_cand = use_lds ? entry_cand_count(d) : 0;
+    float2 cq[PAIR_STAGE_BATCH];
+    uint32_t ck[PAIR_STAGE_BATCH];
+    int cslot[PAIR_STAGE_BATCH], cdd[PAIR_STAGE_BATCH];
+#pragma unroll
+    for (int b = 0; b < PAIR_STAGE_BATCH; b++) {
+        const int i = tix + b * THREADS;
+        cslot[b] = -1;
+        cdd[b] = 0;
+        if (i < n_cand) {
+            cslot[b] = entry_cand_slot(d, i, cdd[b]);
+            cq[b] = pos[cslot[b]];
+            ck[b] = skeys[cslot[b]];
+        }
+    }
+    entry_cells_table<THREADS>(g, g0, g1, s_off, s_gs, s_wave, tix);
     __syncthreads();
-    const bool use_lds = g.total <= cap;
-    if (!use_lds && dense_defer(sink, g, tix)) return;
     if (use_lds) {
-        // 16 lanes per candidate cell, 16 cells per pass, PAIR_STAGE_BATCH passes' loads in flight together
-        for (int cc0 = tix >> 4; cc0 < g.ncells; cc0 += PAIR_STAGE_BATCH * (THREADS / 16)) {
-            float2 v[PAIR_STAGE_BATCH];
-            int dst[PAIR_STAGE_BATCH], src[PAIR_STAGE_BATCH], left[PAIR_STAGE_BATCH];
 #pragma unroll
-            for (int b = 0; b < PAIR_STAGE_BATCH; b++) {
-                const int cc = cc0 + b * (THREADS / 16);
-                left[b] = 0;
-                if (cc < g.ncells) {
-                    dst[b] = s_off[cc] + (tix & 15);
-                    src[b] = s_gs[cc] + (tix & 15);
-                    left[b] = cand_count(s_off, cc) - (tix & 15);
-                    if (left[b] > 0) v[b] = pos[src[b]];
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < PAIR_STAGE_BATCH; b++) {
-                if (left[b] > 0) s_pos[dst[b]] = v[b];
-                for (int k = 16; k < left[b]; k += 16) s_pos[dst[b] + k] = pos[src[b] + k];  // cells with > 16 particles
-            }
+        for (int b = 0; b < PAIR_STAGE_BATCH; b++)
+            if (cslot[b] >= 0) s_pos[entry_cand_dst(c, g, s_off, s_gs, cslot[b], cdd[b], ck[b], cap)] = cq[b];
+        for (int i = tix + PAIR_STAGE_BATCH * THREADS; i < n_cand; i += THREADS) {  // (LDS budgets beyond 4 x THREADS)
+            int dd;
+            const int slot = entry_cand_slot(d, i, dd);
+            s_pos[entry_cand_dst(c, g, s_off, s_gs, slot, dd, skeys[slot], cap)] = pos[slot];
         }
         for (int t = tix; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS)
             s_pos[s_off[3 * (t / PAIR_ROW_PAD) + 3] - PAIR_ROW_PAD + (t % PAIR_ROW_PAD)] =
                 make_float2(__builtin_inff(), __builtin_inff());
         __syncthreads();
     }
+    // (one trip per lane on the LDS path: an entry holds at most THREADS own particles)
     for (int s = g.own_lo + tix; s < g.own_hi; s += THREADS) {
         const bool first = s == g.own_lo + tix;
         const float2 pi = first ? pi0 : pos[s];
@@ -403,46 +467,22 @@ __device__ __forceinline__ void density_rows(const DevConsts& c, const float2* _
 }
 
 template <int THREADS>
-__device__ __forceinline__ void density_tile(const DevConsts& c, const float2* __restrict__ pos,
-                                             const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
-                                             float* __restrict__ rho, float* __restrict__ prs,
-                                             int* __restrict__ ncount, uint32_t* __restrict__ nmask, int n_max,
-                                             int col, int trow, int tile_cells, int cap, const DenseSink& sink,
-                                             float2* s_pos, int* s_off, int* s_gs, int* s_wave, int tix) {
-    const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
-    for (int a = cy0; a < cy1;) {  // (more than one trip only in a compressed region)
-        int h = cy1 - a;
-        TileGeom g;
-        asm volatile("" : "+v"(tix));  // keep thread-index arithmetic inside the loop, see for_each_tile
-        if (tile_setup_fit<THREADS>(c, cell_start, col, a, h, cap, g, s_off, s_gs, s_wave, tix))
-            density_rows<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, g, cap, sink, s_pos, s_off, s_gs,
-                                  tix);
-        a += h;
-        if (a < cy1) __syncthreads();  // the next sub-tile reuses the LDS image
-    }
-}
-
-template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* __restrict__ pos,
                                                            const uint32_t* __restrict__ skeys,
                                                            const int* __restrict__ cell_start,
                                                            float* __restrict__ rho, float* __restrict__ prs,
                                                            int* __restrict__ ncount, uint32_t* __restrict__ nmask,
-                                                           int n_max, TileQueue q, int col_lo, int col_hi,
-                                                           int tile_cells, int cap, DenseSink sink) {
+                                                           int n_max, TileQueue q, int col_lo, int col_hi, int cap,
+                                                           DenseSink sink) {
     extern __shared__ __align__(16) float4 s_dyn[];
     float2* s_pos = reinterpret_cast<float2*>(s_dyn);
     int* s_off = reinterpret_cast<int*>(s_pos + cap);
     int* s_gs = s_off + PAIR_MAXC + 1;
     int* s_wave = s_gs + PAIR_MAXC;
-#ifdef SPH_STAMPS
-    for_each_tile(q, [&](int col, int trow, int tix, int) {
-#else
-    for_each_tile(q, [&](int col, int trow, int tix) {
-#endif
-        if (col < col_lo || col >= col_hi) return;  // (the list may cover the force pass's wider range)
-        density_tile<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, col, trow, tile_cells, cap, sink,
-                              s_pos, s_off, s_gs, s_wave, tix);
+    for_each_tile(q, [&](const TileDesc& d, int tix, int) {
+        if (d.col < col_lo || d.col >= col_hi) return;  // (the list may cover the force pass's wider range)
+        density_entry<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, d, cap, sink, s_pos, s_off, s_gs,
+                               s_wave, tix);
     });
 }
 
@@ -812,50 +852,92 @@ struct OwnParticle {
     }
 };
 
+// One list entry of the force pass.  Prologue as in density_entry: the candidate-cell table, the own particles, their
+// mask words (only as many as the entry's longest stencil range needs) and the candidates' records (contiguous
+// slot ranges straight from the entry) are all requested before the first wait; three barriers in all.
 template <bool FUSE, int THREADS>
-__device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __restrict__ pos,
-                                           const float2* __restrict__ vel, const float* __restrict__ rho,
-                                           const float* __restrict__ prs, const uint32_t* __restrict__ idv,
-                                           const uint32_t* __restrict__ skeys, float2* __restrict__ pos_o,
-                                           float2* __restrict__ vel_o, const TileGeom& g, int cap, float mx, float my,
-                                           float strength, int allow_fast, const uint32_t* __restrict__ nmask,
-                                           int n_max, const DenseSink& sink, PairRec* s_rec, int* s_off, int* s_gs,
-                                           uint8_t* s_q, int tix STAMP_PARAM) {
-    STAMP(1);  // tile_setup done
-    // the first batch of own particles is fetched now, so that the loads overlap the staging below
-    OwnParticle own0;
-    own0.load(g.own_lo + tix, g.own_lo + tix < g.own_hi, pos, vel, rho, prs, idv, skeys);
-    // ... and their mask words (all PAIR_MASK_WORDS of them: how many are meaningful is only known after
-    // the scan) go straight to their LDS slots, s_mask[w * THREADS + tix]
-    uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_q);
-    if (nmask && g.own_lo + tix < g.own_hi) {
-        uint32_t mw[PAIR_MASK_WORDS];
-#pragma unroll
-        for (int k = 0; k < PAIR_MASK_WORDS; k++) mw[k] = nmask[(size_t)k * n_max + g.own_lo + tix];
-#pragma unroll
-        for (int k = 0; k < PAIR_MASK_WORDS; k++) s_mask[k * THREADS + tix] = mw[k];
+__device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __restrict__ pos,
+                                            const float2* __restrict__ vel, const float* __restrict__ rho,
+                                            const float* __restrict__ prs, const uint32_t* __restrict__ idv,
+                                            const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
+                                            float2* __restrict__ pos_o, float2* __restrict__ vel_o, const TileDesc& d,
+                                            int cap, int own_lo_col, int own_hi_col, float mx, float my, float strength,
+                                            int allow_fast, const uint32_t* __restrict__ nmask, int n_max,
+                                            const DenseSink& sink, PairRec* s_rec, int* s_off, int* s_gs, int* s_wave,
+                                            uint8_t* s_q, int tix STAMP_PARAM) {
+    STAMP(0);  // entry start
+    // ghost column of a slab: pass the particles through
+    if (d.col < own_lo_col || d.col >= own_hi_col) {
+        for (int s = d.own_lo + tix; s < d.own_hi; s += THREADS) {
+            vel_o[s] = vel[s];
+            if (FUSE) pos_o[s] = pos[s];
+        }
+        return;
     }
-    __syncthreads();
-    // LDS path: the candidates fit and every stencil range is short enough for the byte queue
-    int too_long = 0;
-    if (tix < g.cy1 - g.cy0) {
-        const int cy = g.cy0 + tix;
-        const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
-        too_long = (s_off[3 * r1 + 3] - PAIR_ROW_PAD - s_off[3 * r0]) > FORCE_MAX_RANGE;
-    }
-    const bool use_lds = !__syncthreads_or(too_long) && g.total <= cap;
+    TileGeom g = entry_geom(c, d);
+    const bool use_lds = (d.info & TILE_DENSE) == 0;
     if (!use_lds && dense_defer(sink, g, tix)) return;
     const float inf = __builtin_inff();
+    int* s_flags = s_wave + 7;
+    uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_q);
+
+    // ---- every global load of the prologue
+    int g0, g1;
+    entry_cells_load(c, cell_start, g, tix, g0, g1);
+    OwnParticle own0;
+    const bool have0 = g.own_lo + tix < g.own_hi;
+    own0.load(g.own_lo + tix, have0, pos, vel, rho, prs, idv, skeys);
+    const int nw_tile = d.info & 0xff;
+    uint32_t mw[PAIR_MASK_WORDS];
+#pragma unroll
+    for (int k = 0; k < PAIR_MASK_WORDS; k++) {
+        mw[k] = 0;
+        if (nmask && have0 && k < nw_tile) mw[k] = nmask[(size_t)k * n_max + g.own_lo + tix];
+    }
+    const int n_cand = use_lds ? entry_cand_count(d) : 0;
+    float2 cq[PAIR_STAGE_BATCH], cw[PAIR_STAGE_BATCH];
+    float cdj[PAIR_STAGE_BATCH], cpj[PAIR_STAGE_BATCH];
+    uint32_t cid[PAIR_STAGE_BATCH], ck[PAIR_STAGE_BATCH];
+    int cslot[PAIR_STAGE_BATCH], cdd[PAIR_STAGE_BATCH];
+#pragma unroll
+    for (int b = 0; b < PAIR_STAGE_BATCH; b++) {
+        const int i = tix + b * THREADS;
+        cslot[b] = -1;
+        cdd[b] = 0;
+        if (i < n_cand) {
+            const int slot = entry_cand_slot(d, i, cdd[b]);
+            cslot[b] = slot;
+            ck[b] = skeys[slot];
+            cq[b] = pos[slot];
+            cw[b] = vel[slot];
+            cdj[b] = rho[slot];
+            cpj[b] = prs[slot];
+            cid[b] = idv[slot];
+        }
+    }
+
+    // ---- candidate-cell table
+    entry_cells_table<THREADS>(g, g0, g1, s_off, s_gs, s_wave, tix);
+    if (tix == 0) *s_flags = 0;
+    __syncthreads();
+    STAMP(1);  // table ready
+
     bool fast = false, by_mask = false;
     if (use_lds) {
-        int unsafe = allow_fast ? 0 : 1;
-        int no_mask = nmask ? 0 : 1;  // k_density's masks: only if no candidate is invalid or non-finite
+        // the lane's mask words go to its LDS slots, s_mask[w * THREADS + tix] (read back by the same lane only)
+        if (nmask) {
+#pragma unroll
+            for (int k = 0; k < PAIR_MASK_WORDS; k++)
+                if (k < nw_tile) s_mask[k * THREADS + tix] = mw[k];
+        }
+        int flags = allow_fast ? 0 : 1;  // bit 0: an operand outside exact_div.h's safe range; bit 1: no masks
+        if (!nmask) flags |= 2;          // k_density's masks: only if no candidate is invalid or non-finite
         auto stage = [&](int dst, float2 q, float2 w, float dj, float pj, uint32_t idj) {
             // exact_div.h is used only if every density / pressure of the tile is in its safe range
-            unsafe |= (dj == 0.0f || !sph_safe_operand(dj) || !sph_safe_operand(pj)) ? 1 : 0;
+            flags |= (dj == 0.0f || !sph_safe_operand(dj) || !sph_safe_operand(pj)) ? 1 : 0;
             // `!particles[j].valid` (sph.cpp:63): an invalid j is staged at +inf so that
             // r2 = +inf >= H*H skips it with the same compare that skips far particles.
-            no_mask |= (!(fabsf(q.x) < inf) || !(fabsf(q.y) < inf) || (idj & SPH_INVALID_BIT)) ? 1 : 0;
+            flags |= (!(fabsf(q.x) < inf) || !(fabsf(q.y) < inf) || (idj & SPH_INVALID_BIT)) ? 2 : 0;
             if (idj & SPH_INVALID_BIT) q = make_float2(inf, inf);
             PairRec rec;
             rec.aux = make_float4(w.x, w.y, dj, pj);
@@ -864,37 +946,15 @@ __device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __r
             rec.pad = 0.0f;
             s_rec[dst] = rec;
         };
-        // 16 lanes per candidate cell, 16 cells per pass, PAIR_STAGE_BATCH passes' loads in flight together
-        for (int cc0 = tix >> 4; cc0 < g.ncells; cc0 += PAIR_STAGE_BATCH * (THREADS / 16)) {
-            float2 q[PAIR_STAGE_BATCH], w[PAIR_STAGE_BATCH];
-            float dj[PAIR_STAGE_BATCH], pj[PAIR_STAGE_BATCH];
-            uint32_t idj[PAIR_STAGE_BATCH];
-            int dst[PAIR_STAGE_BATCH], src[PAIR_STAGE_BATCH], left[PAIR_STAGE_BATCH];
 #pragma unroll
-            for (int b = 0; b < PAIR_STAGE_BATCH; b++) {
-                const int cc = cc0 + b * (THREADS / 16);
-                left[b] = 0;
-                if (cc < g.ncells) {
-                    dst[b] = s_off[cc] + (tix & 15);
-                    src[b] = s_gs[cc] + (tix & 15);
-                    left[b] = cand_count(s_off, cc) - (tix & 15);
-                    if (left[b] > 0) {
-                        q[b] = pos[src[b]];
-                        w[b] = vel[src[b]];
-                        dj[b] = rho[src[b]];
-                        pj[b] = prs[src[b]];
-                        idj[b] = idv[src[b]];
-                    }
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < PAIR_STAGE_BATCH; b++) {
-                if (left[b] > 0) stage(dst[b], q[b], w[b], dj[b], pj[b], idj[b]);
-                for (int k = 16; k < left[b]; k += 16) {  // cells with > 16 particles
-                    const int j = src[b] + k;
-                    stage(dst[b] + k, pos[j], vel[j], rho[j], prs[j], idv[j]);
-                }
-            }
+        for (int b = 0; b < PAIR_STAGE_BATCH; b++)
+            if (cslot[b] >= 0)
+                stage(entry_cand_dst(c, g, s_off, s_gs, cslot[b], cdd[b], ck[b], cap), cq[b], cw[b], cdj[b], cpj[b], cid[b]);
+        for (int i = tix + PAIR_STAGE_BATCH * THREADS; i < n_cand; i += THREADS) {  // (LDS budgets beyond 4 x THREADS)
+            int dd;
+            const int slot = entry_cand_slot(d, i, dd);
+            stage(entry_cand_dst(c, g, s_off, s_gs, slot, dd, skeys[slot], cap), pos[slot], vel[slot], rho[slot], prs[slot],
+                  idv[slot]);
         }
         for (int t = tix; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS) {
             int idx = s_off[3 * (t / PAIR_ROW_PAD) + 3] - PAIR_ROW_PAD + (t % PAIR_ROW_PAD);
@@ -905,20 +965,24 @@ __device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __r
             rec.pad = 0.0f;
             s_rec[idx] = rec;
         }
-        fast = !__syncthreads_or(unsafe);
-        by_mask = !__syncthreads_or(no_mask) && fast;
+        if (flags) atomicOr(s_flags, flags);
+        __syncthreads();
+        const int all = *s_flags;
+        fast = (all & 1) == 0;
+        by_mask = fast && (all & 2) == 0;
     }
     STAMP(2);  // staged
-    STAMP_VAL(5, (unsigned long long)(g.own_hi - g.own_lo) | ((unsigned long long)g.total << 32));
+    STAMP_VAL(5, (unsigned long long)(g.own_hi - g.own_lo) | ((unsigned long long)s_off[g.ncells] << 32));
 
     // All lanes of a wave stay in the loop together (wave-level votes below); lanes without a
-    // particle, or with an invalid one, simply have an empty candidate range.
-    const int n_iter = (g.own_hi - g.own_lo + THREADS - 1) / THREADS;
+    // particle, or with an invalid one, simply have an empty candidate range.  On the LDS path an entry holds
+    // at most THREADS own particles: one trip.
+    const int n_iter = use_lds ? 1 : (g.own_hi - g.own_lo + THREADS - 1) / THREADS;
     for (int it = 0; it < n_iter; it++) {
         const int s = g.own_lo + it * THREADS + tix;
         const bool have = s < g.own_hi;
         OwnParticle own = own0;
-        if (it > 0) own.load(s, have, pos, vel, rho, prs, idv, skeys);  // tiles with more than THREADS particles
+        if (it > 0) own.load(s, have, pos, vel, rho, prs, idv, skeys);
         float2 pi = own.p, vi = own.v;
         const float dens_i = own.d, pres_i = own.pr;
         const bool valid = have && !(own.idv & SPH_INVALID_BIT);
@@ -938,8 +1002,8 @@ __device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __r
                 self = s_off[self_cell] + (s - s_gs[self_cell]);
             }
             if (by_mask)
-                force_by_mask<THREADS>(c, s_rec, s_mask, it > 0 ? nmask + (have ? s : 0) : (const uint32_t*)nullptr, n_max, j,
-                                       (hi - j + 31) >> 5, self, pi, vi, pres_i, fx, fy, tix);
+                force_by_mask<THREADS>(c, s_rec, s_mask, (const uint32_t*)nullptr, n_max, j, (hi - j + 31) >> 5, self, pi, vi,
+                                       pres_i, fx, fy, tix);
             else if (fast)
                 force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
             else
@@ -976,45 +1040,11 @@ __device__ __forceinline__ void force_rows(const DevConsts& c, const float2* __r
 }
 
 template <bool FUSE, int THREADS>
-__device__ __forceinline__ void force_tile(const DevConsts& c, const float2* __restrict__ pos,
-                                           const float2* __restrict__ vel, const float* __restrict__ rho,
-                                           const float* __restrict__ prs, const uint32_t* __restrict__ idv,
-                                           const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
-                                           float2* __restrict__ pos_o, float2* __restrict__ vel_o, int col, int trow,
-                                           int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my,
-                                           float strength, int allow_fast, const uint32_t* __restrict__ nmask,
-                                           int n_max, const DenseSink& sink, PairRec* s_rec, int* s_off, int* s_gs,
-                                           int* s_wave, uint8_t* s_q, int tix STAMP_PARAM) {
-    const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, c.ny);
-    STAMP(0);  // tile start
-    // ghost column of a slab: pass the particles through (cheap test before any setup)
-    if (col < own_lo_col || col >= own_hi_col) {
-        int lo = cell_start[col * c.ny + cy0], hi = cell_start[col * c.ny + cy1];
-        for (int s = lo + tix; s < hi; s += THREADS) {
-            vel_o[s] = vel[s];
-            if (FUSE) pos_o[s] = pos[s];
-        }
-        return;
-    }
-    for (int a = cy0; a < cy1;) {  // (more than one trip only in a compressed region; same sub-tiles as k_density)
-        int h = cy1 - a;
-        TileGeom g;
-        asm volatile("" : "+v"(tix));  // see density_tile
-        if (tile_setup_fit<THREADS>(c, cell_start, col, a, h, cap, g, s_off, s_gs, s_wave, tix))
-            force_rows<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, pos_o, vel_o, g, cap, mx, my, strength, allow_fast,
-                                      nmask, n_max, sink, s_rec, s_off, s_gs, s_q, tix STAMP_ARG);
-        a += h;
-        if (a < cy1) __syncthreads();  // the next sub-tile reuses the LDS image
-    }
-}
-
-
-template <bool FUSE, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_WAVES_MAX, FORCE_WAVES_MAX))) void k_force(
     DevConsts c, const float2* __restrict__ pos, const float2* __restrict__ vel, const float* __restrict__ rho,
     const float* __restrict__ prs, const uint32_t* __restrict__ idv, const uint32_t* __restrict__ skeys,
     const int* __restrict__ cell_start, float2* __restrict__ pos_o, float2* __restrict__ vel_o, TileQueue q, int col_lo,
-    int col_hi, int skip_lo, int skip_hi, int tile_cells, int cap, int own_lo_col, int own_hi_col, float mx, float my,
+    int col_hi, int skip_lo, int skip_hi, int cap, int own_lo_col, int own_hi_col, float mx, float my,
     float strength, int allow_fast, const uint32_t* __restrict__ nmask, int n_max, DenseSink sink) {
     extern __shared__ __align__(16) float4 s_dyn[];
     PairRec* s_rec = reinterpret_cast<PairRec*>(s_dyn);
@@ -1022,8 +1052,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
     int* s_gs = s_off + PAIR_MAXC + 1;
     int* s_wave = s_gs + PAIR_MAXC;
     uint8_t* s_q = reinterpret_cast<uint8_t*>(s_wave + 8);
+    for_each_tile(q, [&](const TileDesc& d, int tix, int t_list) {
 #ifdef SPH_STAMPS
-    for_each_tile(q, [&](int col, int trow, int tix, int t_list) {
         const int stamp_slot = t_list < STAMP_TILES ? t_list : -1;
         if (stamp_slot >= 0 && (tix & 63) == 0) {
             g_stamps[((size_t)stamp_slot * 4 + (tix >> 6)) * 8 + 6] =
@@ -1032,14 +1062,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
             g_stamps[((size_t)stamp_slot * 4 + (tix >> 6)) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
         }
 #else
-    for_each_tile(q, [&](int col, int trow, int tix) {
+        (void)t_list;
 #endif
         // columns [col_lo, col_hi) without [skip_lo, skip_hi): a slab step runs the columns next to the slab
         // boundaries first and the interior in a second launch (sph_force_launch)
-        if (col < col_lo || col >= col_hi || (col >= skip_lo && col < skip_hi)) return;
-        force_tile<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, col, trow, tile_cells, cap,
-                                  own_lo_col, own_hi_col, mx, my, strength, allow_fast, nmask, n_max, sink, s_rec, s_off,
-                                  s_gs, s_wave, s_q, tix STAMP_ARG);
+        if (d.col < col_lo || d.col >= col_hi || (d.col >= skip_lo && d.col < skip_hi)) return;
+        force_entry<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, d, cap, own_lo_col,
+                                   own_hi_col, mx, my, strength, allow_fast, nmask, n_max, sink, s_rec, s_off, s_gs, s_wave,
+                                   s_q, tix STAMP_ARG);
     });
 }
 
@@ -1527,34 +1557,29 @@ int sph_step_reference_order(SphCtx* c, float mx, float my, float strength, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Compacts the non-empty tiles of columns [col0, col0 + ncols) into list[] (see for_each_tile); the grid
-// build normally does this in the tail of its reorder kernel (grid.hip), this kernel is the fallback.
-__global__ __launch_bounds__(256) void k_tile_list(const int* __restrict__ cell_start, int ny, int tile_cells,
-                                                    int tiles_per_col, int col0, int ncols, int* __restrict__ list,
-                                                    int* __restrict__ count) {
-    sph_tile_list_thread(blockIdx.x * blockDim.x + threadIdx.x, cell_start, ny, tile_cells, tiles_per_col, col0, ncols,
-                         list, count);
+// Builds the work list of the pair kernels (sphhip_internal.h: sph_tile_list_thread); the grid build normally does
+// this in the head of its reorder kernel (grid.hip), this kernel is the fallback (another tiling, LDS budget or
+// column range than the list was built for).
+__global__ __launch_bounds__(256) void k_tile_list(const int* __restrict__ cell_start, int nx, int ny, TileListArgs tl,
+                                                    int* __restrict__ err) {
+    sph_tile_list_thread(blockIdx.x * blockDim.x + threadIdx.x, cell_start, nx, ny, tl, err);
 }
 
-// (Re)builds the tile list for the current grid, tiling and column range if it is not current.
+// (Re)builds the tile list for the current grid, tiling, LDS budget and column range if it is not current.
 static int ensure_tile_list(SphCtx* c, TileQueue& q) {
     TileListArgs tl;
     int lo, hi;
     sph_tile_list_args(c, tl, lo, hi);
-    if (!(c->tiles_valid && c->tiles_cells == c->tile_cells && c->tiles_lo == lo && c->tiles_hi == hi)) {
+    if (!sph_tiles_current(c, lo, hi)) {
         HIP_TRY(hipMemsetAsync(tl.count, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_tile_list, dim3((tl.nthreads + 255) / 256), dim3(256), 0, c->stream, c->cell_start, c->dc.ny,
-                           tl.tile_cells, tl.tiles_per_col, tl.col0, tl.ncols, tl.list, tl.count);
+        hipLaunchKernelGGL(k_tile_list, dim3((tl.nthreads + 255) / 256), dim3(256), 0, c->stream, c->cell_start, c->dc.nx,
+                           c->dc.ny, tl, c->d_err);
         LAUNCH_CHECK();
-        c->tiles_valid = true;
-        c->tiles_cells = c->tile_cells;
-        c->tiles_lo = lo;
-        c->tiles_hi = hi;
+        sph_tiles_mark(c, lo, hi);
     }
     q.list = c->tile_list;
     q.count = tl.count;
     q.host_count = c->d_host_tiles;
-    q.tiles_per_col = tl.tiles_per_col;
     q.tile_cells = tl.tile_cells;
     return SPHHIP_OK;
 }
@@ -1583,30 +1608,30 @@ static int pair_grid(SphCtx* c, const void* kern, int threads, size_t lds, int& 
     return SPHHIP_OK;
 }
 
-// Tile height for the coming grid build.  The tuned height (tile_cells_max cells) assumes a few hundred
-// candidates per tile.  In a dense scene (the reference's fixed 1.9 x 1.9 box with thousands of particles:
-// 25-100 per cell) such a tile overflows the LDS budget and the kernels cut it into sub-tiles that one
-// workgroup processes one after the other -- with only a few dozen tiles in the whole grid, most of the
-// GPU idles.  Going by the tile count the last launch reported (mapped host memory, so a step or two old)
-// the host then picks a smaller height: the sub-tiles become tiles of their own.  Only scenes that are
-// both overflowing and short of workgroups are touched; results do not depend on the tiling.
+// Height of the base tiles for the coming grid build.  The device-side list builder cuts a base tile that holds
+// more particles than a workgroup has lanes (or more candidates than the LDS budget) into several entries, so any
+// height is correct; the best one fills the lanes: about pair_threads own particles per entry.  Going by the entry
+// count the last launch reported (mapped host memory, so a step or two old) the host estimates the particles per
+// cell of the occupied region and picks the height from that.  A tiny grid (the reference box has 169 cells) gets
+// one row per workgroup, the shortest critical path.  Results do not depend on the tiling.
 void sph_adapt_tile_cells(SphCtx* c, int n) {
     if (!c->tile_cells_auto) return;
     const int tiles = ((volatile int*)c->h_host_tiles)[0], cells = ((volatile int*)c->h_host_tiles)[1];
     if (tiles <= 0 || cells <= 0 || n <= 0) return;
-    // particles per cell of the listed tiles (a column's last tile may overhang the grid)
-    const int per_col = (c->dc.ny + cells - 1) / cells;
-    const double occ = (double)n / ((double)tiles * ((double)c->dc.ny / per_col));
-    auto cand = [&](int tc) { return occ * 3.0 * (tc + 2); };
     int want = c->tile_cells;
-    const bool starved = (long long)tiles * cells < (long long)8 * c->num_cus * c->tile_cells;  // < 8 tiles per CU
     if ((long long)tiles * cells <= 4ll * c->num_cus) {
-        want = 1;  // a tiny grid (the reference box has 169 cells): one cell per workgroup, the shortest critical path
-    } else if (starved && cand(want) > 0.9 * c->pair_cap) {
-        while (want > 1 && cand(want) > 0.9 * c->pair_cap) want--;
+        want = 1;
     } else {
-        while (want < c->tile_cells_max && cand(want + 1) < 0.6 * c->pair_cap) want++;
-        if (want < c->tile_cells_max && want < c->tile_cells + 2) want = c->tile_cells;  // (no dithering)
+        // own particles per entry of the last list, at `cells` rows per base tile
+        const double per_entry = (double)n / (double)tiles;
+        const double per_row = per_entry / (double)cells;  // (an underestimate where base tiles were cut or trimmed)
+        int fit = (int)(0.94 * c->pair_threads / (per_row > 1e-3 ? per_row : 1e-3));
+        fit = fit < 1 ? 1 : fit > c->tile_cells_max ? c->tile_cells_max : fit;
+        // per_row is only meaningful while most base tiles give one entry: when they are cut (per_entry well below
+        // the lanes although the rows are full) the estimate would keep growing the height; follow it downwards
+        // freely, upwards only while entries are clearly under-filled
+        if (fit < want || per_entry < 0.8 * c->pair_threads) want = fit;
+        if (want > c->tile_cells && want < c->tile_cells + 2 && want < c->tile_cells_max) want = c->tile_cells;  // (no dithering)
     }
     if (want != c->tile_cells) {
         c->tile_cells = want;
@@ -1667,7 +1692,7 @@ int sph_density_launch(SphCtx* c) {
     bool tp = false;
     if ((rc = dense_prepare(c, 0, sink, dq, dense_grid, tp))) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, c->pos, c->keys, c->cell_start, c->rho,
-                       c->prs, c->ncount, c->nmask, c->n_max, q, lo, hi, c->tile_cells, c->pair_cap, sink);
+                       c->prs, c->ncount, c->nmask, c->n_max, q, lo, hi, c->pair_cap, sink);
     LAUNCH_CHECK();
     if (sink.defer) {
         hipLaunchKernelGGL(k_density_dense, dim3(dense_grid), dim3(DENSE_THREADS), pair_lds_bytes(c->pair_cap, false, DENSE_THREADS),
@@ -1720,7 +1745,7 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     const int lo = second ? il : flo, hi = second ? ih : fhi;
     const int skip_lo = part == 1 ? il : 0, skip_hi = part == 1 ? ih : 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
-                       c->cell_start, pout, vout, q, lo, hi, skip_lo, skip_hi, c->tile_cells, c->pair_cap, c->col_lo, c->col_hi,
+                       c->cell_start, pout, vout, q, lo, hi, skip_lo, skip_hi, c->pair_cap, c->col_lo, c->col_hi,
                        mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink);
     LAUNCH_CHECK();
     if (sink.defer) {

@@ -64,8 +64,8 @@ struct SphCtx {
                                  // build drops them (sphhip_pack_halo_async's fast path does not compact)
     int slice_lo = 0, slice_hi = 0;
     int col_lo = 0, col_hi = 0;  // owned columns (default: all)
-    int tile_cells = 12;         // cells of a column per pair-kernel workgroup
-    int tile_cells_max = 12;     // ... its upper bound; sph_adapt_tile_cells picks tile_cells below it for dense scenes
+    int tile_cells = 15;         // rows of a column per base tile of the pair kernels (TileDesc)
+    int tile_cells_max = 16;     // ... its upper bound; sph_adapt_tile_cells picks tile_cells from the scene's cell population
     bool tile_cells_auto = true; // false once SPHHIP_TILE_CELLS / sphhip_set_tuning fixed the tiling
     int pair_cap = 960;          // neighbour candidates staged in LDS per workgroup (4 workgroups of k_force per CU)
     int pair_threads = 256;      // 128 or 256
@@ -96,10 +96,10 @@ struct SphCtx {
     int* digit_total = nullptr;                  // SORT_RADIX (+ SORT_RADIX bases)
     int* scan_tmp = nullptr;                     // block partials of the suffix-min scan
     int* counters = nullptr;                     // small device scratch (compaction counters ...)
-    int* tile_list = nullptr;                    // non-empty tiles of the pair kernels (pairs.hip), <= ncell entries
+    struct TileDesc* tile_list = nullptr;        // work list of the pair kernels: one entry per workgroup pass (see TileDesc)
     int tile_list_cap = 0;                       // allocated entries (a pair-kernel grid never exceeds it: for_each_tile)
     bool tiles_valid = false;                    // ... current for this grid, tiles_cells, [tiles_lo, tiles_hi)
-    int tiles_cells = 0, tiles_lo = 0, tiles_hi = 0;
+    int tiles_cells = 0, tiles_lo = 0, tiles_hi = 0, tiles_cap = 0, tiles_threads = 0;
     int num_cus = 256;
     int* h_host_tiles = nullptr;                 // mapped host ints: tile count of a recent launch (-1: none yet), its tile_cells
     int* d_host_tiles = nullptr;                 // its device address
@@ -173,6 +173,9 @@ struct PhaseScope {
     ~PhaseScope() { sph_phase_end(c, ph); }
 };
 
+// sticky error bits of asynchronous steps (SphCtx::d_err)
+enum { SPH_ERR_HALO_OVERFLOW = 1, SPH_ERR_MSG_BAD = 2, SPH_ERR_CAPACITY = 4, SPH_ERR_OUT_OF_SLAB = 8 };
+
 // ---- small device helpers -------------------------------------------------------------------
 __device__ __forceinline__ int sph_lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -191,39 +194,276 @@ __device__ __forceinline__ int sph_cell_coord(float x, float x0, float inv_cell,
     return c;
 }
 
-// Tiles of the pair kernels are listed in bands of PAIR_BAND_COLS adjacent grid columns (pairs.hip).
-constexpr int PAIR_BAND_COLS = 4;
+constexpr int PAIR_ROW_PAD = 3;       // sentinel records behind every candidate row of a tile's LDS image (pairs.hip)
+constexpr int FORCE_MAX_RANGE = 256;  // longest 3x3 stencil range (LDS records) of the LDS path: 8 mask words / byte queue
 
-// ---- tile list of the pair kernels (pairs.hip: for_each_tile) --------------------------------
-// Thread i of a compaction pass looks at one tile of columns [col0, col0 + ncols), in band-major order,
-// and appends it to list[] if it holds particles; a wave appends its hits with one atomic.
-__device__ __forceinline__ void sph_tile_list_thread(int i, const int* __restrict__ cell_start, int ny,
-                                                     int tile_cells, int tiles_per_col, int col0, int ncols,
-                                                     int* __restrict__ list, int* __restrict__ count) {
-    const int per_band = PAIR_BAND_COLS * tiles_per_col;
-    const int band = i / per_band, r = i % per_band;
-    const int trow = r / PAIR_BAND_COLS, col = col0 + band * PAIR_BAND_COLS + r % PAIR_BAND_COLS;
-    bool hit = false;
-    if (col < col0 + ncols) {
-        const int cy0 = trow * tile_cells, cy1 = min(cy0 + tile_cells, ny);
-        hit = cell_start[col * ny + cy1] > cell_start[col * ny + cy0];
-    }
-    const unsigned long long hits = __ballot(hit);
-    const int lane = sph_lane_id();
-    int base = 0;
-    if (lane == 0 && hits) base = atomicAdd(count, __popcll(hits));
-    base = __shfl(base, 0, 64);
-    if (hit) list[base + __popcll(hits & ((1ull << lane) - 1ull))] = col * tiles_per_col + trow;
-}
+// ---- tile list of the pair kernels ----------------------------------------------------------------
+// One entry = one workgroup's work: the particles of rows [cy0, cy1) of grid column `col` (one contiguous slot
+// range, the keys are column-major) and their neighbour candidates, rows [cy0-1, cy1+1) of columns col-1..col+1
+// (one contiguous slot range per column).  Everything a pair kernel needs to start its global loads is in the
+// entry, so the loads of the particle data do not wait for a round trip through the cell table first.
+struct __align__(16) TileDesc {
+    int col, cy0, cy1;
+    int info;            // bits 0..7: mask words the longest stencil range of the tile needs; bit 8: dense (see below)
+    int own_lo, own_hi;  // slots of the own particles
+    int c_lo[3], c_hi[3];  // slots of the candidates in columns col-1, col, col+1 (empty outside the grid)
+};
+static_assert(sizeof(TileDesc) == 48, "TileDesc");
+constexpr int TILE_DENSE = 1 << 8;
+constexpr int TILE_FAST_ROWS = 16;  // base tiles up to this height are checked with one batch of loads (sph_tile_list_thread)
 
+// The list is built on the device right after the cell table (tail of the grid build).  Thread i looks at one BASE
+// tile -- `tile_cells` rows of one column, column-major order -- and cuts it into entries such that every entry
+//   * holds at most `max_own` own particles (one lane each, a single pass over the workgroup),
+//   * stages at most `cap` LDS records (candidates + PAIR_ROW_PAD sentinels per row),
+//   * has no stencil range longer than FORCE_MAX_RANGE,
+// skipping rows without particles at its ends; a single row that violates one of these becomes an entry of its own
+// with TILE_DENSE set (the dense sub-tile kernels take those).  Base tiles that fit as a whole -- the normal case,
+// the host adapts `tile_cells` to the scene -- give one entry.  A wave appends its entries with one atomic.
 struct TileListArgs {
-    int tile_cells, tiles_per_col, col0, ncols, nthreads;
-    int* list;
+    int tile_cells, tiles_per_col, col0, ncols, nthreads, cap, max_own, list_cap;
+    TileDesc* list;
     int* count;
 };
 
-// sticky error bits of asynchronous steps (SphCtx::d_err)
-enum { SPH_ERR_HALO_OVERFLOW = 1, SPH_ERR_MSG_BAD = 2, SPH_ERR_CAPACITY = 4, SPH_ERR_OUT_OF_SLAB = 8 };
+struct TileRow {  // one grid row of a base tile's neighbourhood
+    int own;      // particles in (col, y)
+    int cand;     // particles in (col-1..col+1, y) + PAIR_ROW_PAD; 0 outside the grid
+};
+
+__device__ __forceinline__ TileRow sph_tile_row(const int* __restrict__ cell_start, int nx, int ny, int col, int y) {
+    TileRow r = {0, 0};
+    if (y < 0 || y >= ny) return r;
+    const int k = col * ny + y;
+    r.own = cell_start[k + 1] - cell_start[k];
+    r.cand = r.own + PAIR_ROW_PAD;
+    if (col > 0) r.cand += cell_start[k - ny + 1] - cell_start[k - ny];
+    if (col + 1 < nx) r.cand += cell_start[k + ny + 1] - cell_start[k + ny];
+    return r;
+}
+
+__device__ __forceinline__ TileDesc sph_tile_desc(const int* __restrict__ cell_start, int nx, int ny, int col, int a, int b,
+                                                  int info) {
+    TileDesc d;
+    d.col = col;
+    d.cy0 = a;
+    d.cy1 = b;
+    d.info = info;
+    d.own_lo = cell_start[col * ny + a];
+    d.own_hi = cell_start[col * ny + b];
+    const int ylo = a > 0 ? a - 1 : 0, yhi = b < ny ? b + 1 : ny;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int cc = col - 1 + k;
+        const bool in = cc >= 0 && cc < nx;
+        d.c_lo[k] = in ? cell_start[cc * ny + ylo] : 0;
+        d.c_hi[k] = in ? cell_start[cc * ny + yhi] : 0;
+    }
+    return d;
+}
+
+// Cutting a base tile into entries, one row at a time (rows in ascending order): the state of the entry being grown
+// and the step that looks at row y given the candidate counts of rows y-1, y, y+1.  emit(a, b, info) is called for
+// every finished entry [a, b).
+struct TileCut {
+    int a = -1;     // first row of the entry being grown (-1: none)
+    int last = -1;  // its last row with particles
+    int own = 0;    // own particles in [a, last]
+    int total = 0;  // LDS records of rows [a-1, y-1] (y: the row being looked at)
+    int nw = 0;     // mask words of the longest stencil range among rows [a, last]
+    int n_out = 0;
+    template <class Emit>
+    __device__ __forceinline__ void row(int y, int prev_cand, int cur_own, int cur_cand, int next_cand, int cap, int max_own,
+                                        Emit&& emit) {
+        const int len = prev_cand + cur_cand + next_cand - PAIR_ROW_PAD;  // stencil range of the particles of row y
+        const bool row_fits = cur_own <= max_own && prev_cand + cur_cand + next_cand <= cap && len <= FORCE_MAX_RANGE;
+        if (cur_own > 0) {
+            // can row y join the entry [a, last]?  (rows between last and y are empty but are staged as well)
+            if (a >= 0 && (!row_fits || own + cur_own > max_own || total + cur_cand + next_cand > cap)) {
+                emit(a, last + 1, nw);
+                n_out++;
+                a = -1;
+            }
+            if (!row_fits) {
+                emit(y, y + 1, TILE_DENSE);
+                n_out++;
+            } else {
+                if (a < 0) {
+                    a = y;
+                    own = 0;
+                    nw = 0;
+                    total = prev_cand;
+                }
+                own += cur_own;
+                last = y;
+                nw = max(nw, (len + 31) >> 5);
+            }
+        }
+        if (a >= 0) total += cur_cand;  // rows [a-1, y] are staged if the entry goes on beyond y
+    }
+    template <class Emit>
+    __device__ __forceinline__ int finish(Emit&& emit) {
+        if (a >= 0) {
+            emit(a, last + 1, nw);
+            n_out++;
+        }
+        return n_out;
+    }
+};
+
+// Walks the rows of base tile (col, rows [cy0, cy1)) reading the cell table row by row (one dependent memory round
+// trip per row: only for base tiles higher than TILE_FAST_ROWS).  Returns the number of entries.
+template <class Emit>
+__device__ __forceinline__ int sph_tile_walk(const int* __restrict__ cell_start, int nx, int ny, int col, int cy0, int cy1,
+                                             int cap, int max_own, Emit&& emit) {
+    TileCut cut;
+    TileRow prev = sph_tile_row(cell_start, nx, ny, col, cy0 - 1), cur = sph_tile_row(cell_start, nx, ny, col, cy0);
+    for (int y = cy0; y < cy1; y++) {
+        const TileRow next = sph_tile_row(cell_start, nx, ny, col, y + 1);
+        cut.row(y, prev.cand, cur.own, cur.cand, next.cand, cap, max_own, emit);
+        prev = cur;
+        cur = next;
+    }
+    return cut.finish(emit);
+}
+
+// The same walk over per-row counts held in registers (row j <-> grid row cy0 - 1 + j; fully unrolled, static indices).
+template <int R, class Emit>
+__device__ __forceinline__ int sph_tile_walk_regs(const int (&own_r)[R + 2], const int (&cand)[R + 2], int rows, int cy0,
+                                                  int cap, int max_own, Emit&& emit) {
+    TileCut cut;
+#pragma unroll
+    for (int j = 1; j <= R; j++)
+        if (j <= rows) cut.row(cy0 - 1 + j, cand[j - 1], own_r[j], cand[j], cand[j + 1], cap, max_own, emit);
+    return cut.finish(emit);
+}
+
+__device__ __forceinline__ void sph_tile_list_thread(int i, const int* __restrict__ cell_start, int nx, int ny,
+                                                     const TileListArgs& tl, int* __restrict__ err) {
+    // Column-major: consecutive lanes take vertically adjacent base tiles of one column, whose cell table entries
+    // are contiguous (a wave's loads below touch ~30 cache lines each instead of 64 with one column per lane).
+    // The list inherits that order: an XCD's chunk of it is a block of adjacent columns.
+    const int trow = i % tl.tiles_per_col, col = tl.col0 + i / tl.tiles_per_col;
+    int k = 0, cy0 = 0, cy1 = 0;
+    TileDesc first;
+    unsigned cut_starts = 0, cut_ends = 0;  // a cut base tile (fast path): first / last row of every entry
+    unsigned long long cut_info = 0;        // ... 4 bits per first row: mask words, 15 = dense
+    if (i < tl.nthreads && col < tl.col0 + tl.ncols) {
+        cy0 = trow * tl.tile_cells;
+        cy1 = min(cy0 + tl.tile_cells, ny);
+        bool walk = true;
+        if (tl.tile_cells <= TILE_FAST_ROWS) {
+            // Fast path (the normal case: the base tile fits as a whole).  All boundaries of the tile's neighbourhood
+            // are fetched with independent loads -- one memory round trip -- and the three limits are checked in
+            // registers; only a base tile that has to be cut takes the row-by-row walk below.
+            const int rows = cy1 - cy0;
+            int b[3][TILE_FAST_ROWS + 3];  // b[k][j] = cell_start of (col-1+k, cy0-1+j), rows clamped to [0, ny]
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                const int cc = col - 1 + kk;
+                const bool in = cc >= 0 && cc < nx;
+#pragma unroll
+                for (int j = 0; j < TILE_FAST_ROWS + 3; j++) {
+                    const int y = min(max(cy0 - 1 + j, 0), ny);
+                    b[kk][j] = (in && j <= rows + 2) ? cell_start[cc * ny + y] : 0;
+                }
+            }
+            int cand[TILE_FAST_ROWS + 2], own_r[TILE_FAST_ROWS + 2];  // row j <-> y = cy0-1+j
+            int own = 0, total = 0;
+#pragma unroll
+            for (int j = 0; j < TILE_FAST_ROWS + 2; j++) {
+                const int y = cy0 - 1 + j;
+                const bool row_in = j <= rows + 1 && y >= 0 && y < ny;
+                own_r[j] = (j >= 1 && j <= rows) ? b[1][j + 1] - b[1][j] : 0;
+                cand[j] = row_in ? (b[0][j + 1] - b[0][j]) + (b[1][j + 1] - b[1][j]) + (b[2][j + 1] - b[2][j]) + PAIR_ROW_PAD : 0;
+                own += own_r[j];
+                total += cand[j];
+            }
+            int maxlen = 0;
+#pragma unroll
+            for (int j = 1; j <= TILE_FAST_ROWS; j++)
+                if (own_r[j] > 0) maxlen = max(maxlen, cand[j - 1] + cand[j] + cand[j + 1] - PAIR_ROW_PAD);
+            walk = false;
+            if (own == 0) {
+                // empty base tile: no entry
+            } else if (!(own <= tl.max_own && total <= tl.cap && maxlen <= FORCE_MAX_RANGE)) {
+                // to be cut: the cuts are noted in bit masks over the tile's rows (written out below)
+                k = sph_tile_walk_regs<TILE_FAST_ROWS>(own_r, cand, rows, cy0, tl.cap, tl.max_own, [&](int a, int e, int info) {
+                    cut_starts |= 1u << (a - cy0);
+                    cut_ends |= 1u << (e - 1 - cy0);
+                    cut_info |= (unsigned long long)((info & TILE_DENSE) ? 15 : info) << (4 * (a - cy0));
+                });
+            } else {
+                k = 1;
+                first.col = col;
+                first.cy0 = cy0;
+                first.cy1 = cy1;
+                first.info = (maxlen + 31) >> 5;
+                first.own_lo = b[1][1];
+                int own_hi = 0, hi0 = 0, hi1 = 0, hi2 = 0;
+#pragma unroll
+                for (int j = 0; j < TILE_FAST_ROWS + 3; j++) {
+                    if (j == rows + 1) own_hi = b[1][j];
+                    if (j == rows + 2) {  // (row cy1 + 1, clamped to ny: the end of the candidate rows)
+                        hi0 = b[0][j];
+                        hi1 = b[1][j];
+                        hi2 = b[2][j];
+                    }
+                }
+                first.own_hi = own_hi;
+                first.c_lo[0] = b[0][0];
+                first.c_lo[1] = b[1][0];
+                first.c_lo[2] = b[2][0];
+                first.c_hi[0] = hi0;
+                first.c_hi[1] = hi1;
+                first.c_hi[2] = hi2;
+            }
+        }
+        if (walk && !(cell_start[col * ny + cy1] > cell_start[col * ny + cy0])) walk = false;  // empty base tile
+        if (walk) {
+            bool have_first = false;  // (only the first entry is kept in this pass)
+            k = sph_tile_walk(cell_start, nx, ny, col, cy0, cy1, tl.cap, tl.max_own, [&](int a, int b, int info) {
+                if (!have_first) first = sph_tile_desc(cell_start, nx, ny, col, a, b, info);
+                have_first = true;
+            });
+        }
+    }
+    // exclusive prefix of k over the wave, one atomic for the wave's total
+    const int lane = sph_lane_id();
+    int incl = k;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    const int wave_total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane == 63 && wave_total) base = atomicAdd(tl.count, wave_total);
+    base = __shfl(base, 63, 64) + incl - k;
+    if (k == 0) return;
+    if (base + k > tl.list_cap) {  // (cannot happen: the list holds an entry per particle)
+        atomicOr(err, SPH_ERR_CAPACITY);
+        return;
+    }
+    if (cut_starts) {  // a base tile that was cut (fast path): one entry per noted cut
+        for (int j = 0; cut_starts; j++) {
+            const int ra = __ffs(cut_starts) - 1, re = __ffs(cut_ends) - 1;
+            cut_starts &= cut_starts - 1;
+            cut_ends &= cut_ends - 1;
+            const int inf4 = (int)((cut_info >> (4 * ra)) & 15);
+            tl.list[base + j] = sph_tile_desc(cell_start, nx, ny, col, cy0 + ra, cy0 + re + 1, inf4 == 15 ? TILE_DENSE : inf4);
+        }
+    } else if (k == 1) {
+        tl.list[base] = first;
+    } else {  // a base tile higher than TILE_FAST_ROWS that was cut: walk it again and write the entries
+        int j = 0;
+        sph_tile_walk(cell_start, nx, ny, col, cy0, cy1, tl.cap, tl.max_own, [&](int a, int b, int info) {
+            tl.list[base + j] = sph_tile_desc(cell_start, nx, ny, col, a, b, info);
+            j++;
+        });
+    }
+}
+
 
 constexpr int SPH_TILE_COUNT_SLOT = 56;  // SphCtx::counters[56]: number of listed tiles
 constexpr int SPH_N_SORTED_SLOT = 57;    // counters[57]: particle count after the last grid build
@@ -247,8 +487,24 @@ static inline void sph_tile_list_args(const SphCtx* c, TileListArgs& tl, int& lo
     tl.tiles_per_col = (c->dc.ny + c->tile_cells - 1) / c->tile_cells;
     tl.col0 = lo;
     tl.ncols = hi - lo;
-    const int nbands = (hi - lo + PAIR_BAND_COLS - 1) / PAIR_BAND_COLS;
-    tl.nthreads = nbands * PAIR_BAND_COLS * tl.tiles_per_col;
+    tl.nthreads = (hi - lo) * tl.tiles_per_col;
+    tl.cap = c->pair_cap;
+    tl.max_own = c->pair_threads;
+    tl.list_cap = c->tile_list_cap;
     tl.list = c->tile_list;
     tl.count = c->counters + SPH_TILE_COUNT_SLOT;
+}
+
+// The tile list in c->tile_list is current for this grid if it was built with these settings.
+static inline bool sph_tiles_current(const SphCtx* c, int lo, int hi) {
+    return c->tiles_valid && c->tiles_cells == c->tile_cells && c->tiles_lo == lo && c->tiles_hi == hi &&
+           c->tiles_cap == c->pair_cap && c->tiles_threads == c->pair_threads;
+}
+static inline void sph_tiles_mark(SphCtx* c, int lo, int hi) {
+    c->tiles_valid = true;
+    c->tiles_cells = c->tile_cells;
+    c->tiles_lo = lo;
+    c->tiles_hi = hi;
+    c->tiles_cap = c->pair_cap;
+    c->tiles_threads = c->pair_threads;
 }
