@@ -40,6 +40,13 @@ __device__ __forceinline__ float sph_div_core(float a, float b, float y) {
     return __builtin_fmaf(r1, y, q1);
 }
 
+// 1.0f / b given y = sph_rcp_refined(b): ONE correction step is enough for the reciprocal -- checked for every
+// float of the safe range by sphhip_selftest_division (671 M values, 0 mismatches; tools/ubench/div_probe.hip).
+__device__ __forceinline__ float sph_rcp_core(float b, float y) {
+    float r = __builtin_fmaf(-b, y, 1.0f);
+    return __builtin_fmaf(r, y, y);
+}
+
 // the same with the hardware's special-case fixup (0, inf, NaN operands behave like `/`)
 __device__ __forceinline__ float sph_div_with_rcp(float a, float b, float y) {
     return __builtin_amdgcn_div_fixupf(sph_div_core(a, b, y), b, a);
@@ -48,22 +55,21 @@ __device__ __forceinline__ float sph_div_with_rcp(float a, float b, float y) {
 // 1.0f / b
 __device__ __forceinline__ float sph_rcp_exact(float b, float y) { return sph_div_with_rcp(1.0f, b, y); }
 
-// sqrt(x) from one v_rsq_f32 (Goldschmidt iteration + one residual correction): correctly rounded for
-// every float of [SPH_SQRT_LO, SPH_SAFE_HI] (checked exhaustively by sphhip_selftest_division), without
-// the denormal-range scaling and compare/select fix-ups of hipcc's generic sqrtf.  Outside that range
-// (0, denormals, inf) the result is garbage: callers clamp (k_force) or use sph_sqrt_exact.
-// Also returns y = sph_rcp_refined(s), the `y` of sph_div_core(., s, y); the self-test checks 1/s and
-// a/s through it for every x.  (Neither the Goldschmidt by-product 2h nor a Newton step from the v_rsq
-// value can replace that v_rcp: with either, 1/s came out wrong for the 100 roots s = 1.11..1b * 2^k
-// of the range -- a tie that only a seed rounded upward resolves.)
+// sqrt(x) from one v_rsq_f32 and ONE residual correction, g = x*r; g += (x - g*g) * (r/2): correctly rounded for
+// every float of [SPH_SQRT_LO, SPH_SAFE_HI] (checked exhaustively by sphhip_selftest_division and
+// tools/ubench/div_probe.hip: 839 M values, 0 mismatches -- the Goldschmidt iteration the first version ran in
+// front of the correction is not needed), without the denormal-range scaling and compare/select fix-ups of hipcc's
+// generic sqrtf.  Outside that range (0, denormals, inf) the result is garbage: callers clamp (k_force) or use
+// sph_sqrt_exact.
+// Also returns y = sph_rcp_refined(s), the `y` of sph_div_core(., s, y) / sph_rcp_core(s, y); the self-test checks
+// 1/s and a/s through it for every x.  (Neither the by-product r/2 nor a Newton step from the v_rsq value can
+// replace that v_rcp: with either, 1/s came out wrong for the 100 roots s = 1.11..1b * 2^k of the range -- a tie
+// that only a seed rounded upward resolves.)
 #define SPH_SQRT_LO 8.67361738e-19f /* 2^-60 */
 __device__ __forceinline__ float sph_sqrt_core(float x, float& y) {
     float r = __builtin_amdgcn_rsqf(x);
     float g = x * r;
     float h = 0.5f * r;
-    float e = __builtin_fmaf(-h, g, 0.5f);
-    g = __builtin_fmaf(g, e, g);
-    h = __builtin_fmaf(h, e, h);
     float d = __builtin_fmaf(-g, g, x);
     g = __builtin_fmaf(d, h, g);
     y = sph_rcp_refined(g);

@@ -513,7 +513,7 @@ __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx
 #pragma unroll
         for (int u = 0; u < U; u++) r_len[u] = sph_sqrt_core(fmaxf(r2[u], SPH_SQRT_LO), yr[u]);  // sph.cpp:67
 #pragma unroll
-        for (int u = 0; u < U; u++) inv_r[u] = sph_div_core(1.0f, r_len[u], yr[u]);  // 1.0f / r_len, sph.cpp:31
+        for (int u = 0; u < U; u++) inv_r[u] = sph_rcp_core(r_len[u], yr[u]);  // 1.0f / r_len, sph.cpp:31
 #pragma unroll
         for (int u = 0; u < U; u++) {
             float term = c.h - r_len[u];
@@ -777,7 +777,9 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
             if (k < nw) s_mask[k * THREADS + tid] = mask_col[(size_t)k * n_max];
     }
     int w = 0;
-    int base = lo;  // LDS index of the candidate in bit 31 of the current word
+    // byte offset (32-byte records) of the candidate in the top bit of the current word
+    int base32 = lo * (int)sizeof(PairRec);
+    const int self32 = self * (int)sizeof(PairRec);
     uint32_t m = 0, m_next = 0;
     if (nw > 0) m = s_mask[tid];
     if (nw > 1) m_next = s_mask[THREADS + tid];
@@ -785,16 +787,19 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
     auto fetch = [&](PairGroup& g) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
+            // (Measured dead end: moving the empty-word case entirely into the refill branch -- no compare / select per
+            // pop, five VALU operations instead of eight -- made the kernel 9 % slower: the extra branch structure costs
+            // more issue slots than the three operations save.)
             if (m == 0 && w + 1 < nw) {
                 w++;
-                base += 32;
+                base32 += 32 * (int)sizeof(PairRec);
                 m = m_next;
                 if (w + 1 < nw) m_next = s_mask[(w + 1) * THREADS + tid];
             }
             const int b = __builtin_clz(m | 1u);  // (m == 0: any value, the slot evaluates the particle itself)
-            const int jj = (m != 0) ? base + b : self;
+            const int off = (m != 0) ? base32 + (b << 5) : self32;
             m &= 0x7fffffffu >> b;
-            const float4* rec = reinterpret_cast<const float4*>(s_rec + jj);
+            const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + off);
             g.aux[u] = rec[0];
             g.pq[u] = rec[1];
         }
@@ -1037,6 +1042,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
         }
     }
     STAMP(4);  // epilogue done
+    STAMP_VAL(6, __builtin_amdgcn_s_memrealtime());
 }
 
 template <bool FUSE, int THREADS>
@@ -1056,9 +1062,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
 #ifdef SPH_STAMPS
         const int stamp_slot = t_list < STAMP_TILES ? t_list : -1;
         if (stamp_slot >= 0 && (tix & 63) == 0) {
-            g_stamps[((size_t)stamp_slot * 4 + (tix >> 6)) * 8 + 6] =
-                (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) |  // HW_REG_XCC_ID
-                ((unsigned long long)blockIdx.x << 32);
             g_stamps[((size_t)stamp_slot * 4 + (tix >> 6)) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
         }
 #else
@@ -1610,10 +1613,15 @@ static int pair_grid(SphCtx* c, const void* kern, int threads, size_t lds, int& 
 
 // Height of the base tiles for the coming grid build.  The device-side list builder cuts a base tile that holds
 // more particles than a workgroup has lanes (or more candidates than the LDS budget) into several entries, so any
-// height is correct; the best one fills the lanes: about pair_threads own particles per entry.  Going by the entry
-// count the last launch reported (mapped host memory, so a step or two old) the host estimates the particles per
-// cell of the occupied region and picks the height from that.  A tiny grid (the reference box has 169 cells) gets
-// one row per workgroup, the shortest critical path.  Results do not depend on the tiling.
+// height is correct; the best one fills the lanes: about pair_threads own particles per entry (both pair kernels
+// are VALU-bound, an idle lane is lost time).  Going by the entry count the last launch reported (mapped host
+// memory, so a step or two old) the host estimates the particles per row of the occupied region and picks the
+// height from that.  A tiny grid (the reference box has 169 cells) gets one row per workgroup, the shortest
+// critical path.  Results do not depend on the tiling.
+// (Measured dead end: choosing the height so that the entry count lands just below a whole number of rounds of
+// resident workgroups -- 13 instead of 15 rows on the 1M dam break -- made k_force 19 % slower: the kernel is bound
+// by VALU throughput, not by rounds; the last, partly filled round runs faster per tile, and shorter tiles leave
+// lanes idle.)
 void sph_adapt_tile_cells(SphCtx* c, int n) {
     if (!c->tile_cells_auto) return;
     const int tiles = ((volatile int*)c->h_host_tiles)[0], cells = ((volatile int*)c->h_host_tiles)[1];
@@ -1625,7 +1633,7 @@ void sph_adapt_tile_cells(SphCtx* c, int n) {
         // own particles per entry of the last list, at `cells` rows per base tile
         const double per_entry = (double)n / (double)tiles;
         const double per_row = per_entry / (double)cells;  // (an underestimate where base tiles were cut or trimmed)
-        int fit = (int)(0.94 * c->pair_threads / (per_row > 1e-3 ? per_row : 1e-3));
+        int fit = (int)(0.95 * c->pair_threads / (per_row > 1e-3 ? per_row : 1e-3));
         fit = fit < 1 ? 1 : fit > c->tile_cells_max ? c->tile_cells_max : fit;
         // per_row is only meaningful while most base tiles give one entry: when they are cut (per_entry well below
         // the lanes although the rows are full) the estimate would keep growing the height; follow it downwards

@@ -20,7 +20,8 @@ __global__ void k_check_rcp(unsigned lo_bits, unsigned hi_bits, unsigned long lo
             float x = __uint_as_float((unsigned)b | (sgn ? 0x80000000u : 0u));
             float want = 1.0f / x;
             float got = sph_div_core(1.0f, x, sph_rcp_refined(x));  // as k_force uses it: no special-case fixup
-            nbad += (__float_as_uint(want) != __float_as_uint(got)) ? 1 : 0;
+            float got1 = sph_rcp_core(x, sph_rcp_refined(x));       // ... and the one-correction form it uses for 1 / r_len
+            nbad += (__float_as_uint(want) != __float_as_uint(got) || __float_as_uint(want) != __float_as_uint(got1)) ? 1 : 0;
         }
     }
     if (nbad) atomicAdd(bad, nbad);
@@ -85,6 +86,7 @@ __global__ void k_check_sqrt(unsigned lo_bits, unsigned hi_bits, unsigned long l
         float a = rnd_safe(splitmix(b), -30, 24);
         if (x != 0.0f) {
             ok = ok && (__float_as_uint(1.0f / want) == __float_as_uint(sph_div_core(1.0f, s, y)));
+            ok = ok && (__float_as_uint(1.0f / want) == __float_as_uint(sph_rcp_core(s, y)));
             ok = ok && (__float_as_uint(a / want) == __float_as_uint(sph_div_core(a, s, y)));
         }
         nbad += ok ? 0 : 1;

@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/variants/$NAME
 mkdir -p "$OUT"
 cd "$ROOT/sph_amd/csrc"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result $EXTRA"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-result $EXTRA"
 for f in ctx grid pairs selftest; do
   /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o "$OUT/$f.o" &
 done

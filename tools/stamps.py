@@ -32,24 +32,22 @@ print("tiles stamped:", used.sum())
 own = b[:, 0, 5] & 0xFFFFFFFF
 tot = b[:, 0, 5] >> 32
 print("own particles per tile: mean %.1f max %d; candidates: mean %.1f max %d" % (own.mean(), own.max(), tot.mean(), tot.max()))
-names = ["setup", "stage", "loop", "epilogue", "whole"]
+names = ["table", "stage", "loop", "epilogue", "whole"]
 for w in range(4):
     t = b[:, w, :5]
     ok = (t[:, 0] != 0) & (t[:, 4] != 0)
     d = np.stack([t[ok, 1] - t[ok, 0], t[ok, 2] - t[ok, 1], t[ok, 3] - t[ok, 2], t[ok, 4] - t[ok, 3], t[ok, 4] - t[ok, 0]], 1)
     print("wave %d (%d tiles):" % (w, ok.sum()), "  ".join("%s p50 %d p90 %d mean %.0f" % (n, np.percentile(d[:, i], 50), np.percentile(d[:, i], 90), d[:, i].mean()) for i, n in enumerate(names)))
-# timeline in real time (100 MHz ticks) of tile starts; whole-tile length in shader cycles
+# timeline in real time (100 MHz ticks) of tile starts; shader clock = s_memtime cycles per s_memrealtime tick
 rt = b[:, 0, 7]
 rt0 = rt.min()
 start_us = (rt - rt0) / 100.0
-whole = (b[:, :3, 4].max(1) - b[:, 0, 0])
-print("launch span by tile starts: %.1f us; last tile start at %.1f us" % (start_us.max(), start_us.max()))
+end_us = (b[:, :, 6].max(1) - rt0) / 100.0
+whole = (b[:, 0, 4] - b[:, 0, 0])
+real = (b[:, 0, 6] - b[:, 0, 7])
+ok = real > 0
+print("shader clock (s_memtime cycles per us of s_memrealtime): median %.0f MHz" % np.median(whole[ok] / (real[ok] / 100.0)))
+print("launch: last tile start at %.1f us, last end at %.1f us" % (start_us.max(), end_us.max()))
 hist, edges = np.histogram(start_us, bins=12)
 print("tile starts per %.1f-us bin:" % (edges[1] - edges[0]), hist.tolist())
-xcc = b[:, 0, 6] & 0xF
-print("tiles per XCC:", np.bincount(xcc, minlength=8).tolist())
-# shader clock estimate: cycles of the whole tile vs real time between this tile's start and the next stamp is not
-# available per tile; use the ratio over the launch
-cyc_span = b[:, :3, 4].max() - b[:, 0, 0].min()
-print("launch span in shader cycles (s_memtime): %d" % cyc_span)
-print("mean tile length %.0f cycles, p90 %.0f" % (whole.mean(), np.percentile(whole, 90)))
+print("mean tile length %.0f cycles = %.1f us, p90 %.0f" % (whole.mean(), (real[ok] / 100.0).mean(), np.percentile(whole, 90)))
