@@ -33,7 +33,11 @@ from sph_amd import scenes  # noqa: E402
 from sph_amd.solver import Solver  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X peak FP32 vector (MI355X_MICROARCH.md)
 FORCE_BYTES_PER_PARTICLE = 40  # fused force + integrate, SURVEY.md 8(d)
+# algorithmic flops, SURVEY.md 8(d): per stencil candidate 7 (2 sub, 2 mul, add, cmp, select), per in-range density
+# pair +6, per in-range force pair +45 (div and sqrt counted as 1 each), per particle epilogue ~25
+FLOP_CANDIDATE, FLOP_DENSITY_PAIR, FLOP_FORCE_PAIR, FLOP_EPILOGUE = 7, 6, 45, 25
 
 WORKLOADS = {
     # name: (kind, lattice columns per GPU, rows)
@@ -94,6 +98,81 @@ def cpu_baseline(n_gpus):
     return base, extra
 
 
+def stencil_candidates(solver, drv):
+    """Sum over particles of the population of their 3x3 cell stencil (the candidates a cell-list pass tests), from
+    the cell table of the current grid.  Host numpy, off the timed path."""
+    solver.buildNeighbors()
+    _, _, cs, ce = solver.cells()
+    cnt = (ce - cs).astype(np.int64).reshape(drv.nx, drv.ny)
+    acc = np.zeros_like(cnt)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            sx0, sx1 = max(0, dx), drv.nx + min(0, dx)
+            sy0, sy1 = max(0, dy), drv.ny + min(0, dy)
+            acc[sx0 - dx:sx1 - dx, sy0 - dy:sy1 - dy] += cnt[sx0:sx1, sy0:sy1]
+    return int((cnt * acc).sum())
+
+
+def force_rooflines(n_local, force_avg_s, pairs_local, cand_local, traffic=None, valu=None):
+    """The two roofline blocks of the dominant kernel (fused force + integrate): HBM by algorithmic bytes, and FP32
+    vector by SURVEY.md 8(d)'s algorithmic flop counts (the bound that actually applies at ~50 neighbours)."""
+    achieved = FORCE_BYTES_PER_PARTICLE * n_local / force_avg_s / 1e9 if force_avg_s > 0 else 0.0
+    hbm = {
+        "kernel": "k_force<fused integrate>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": force_avg_s * 1e3,
+        "algorithmic_bytes_per_launch": FORCE_BYTES_PER_PARTICLE * n_local, "valu": valu,
+        "note": "pair kernels are VALU-bound at ~50 neighbours (no MFMA: irregular gathers); see roofline_valu and DESIGN.md",
+    }
+    flops = FLOP_CANDIDATE * cand_local + FLOP_FORCE_PAIR * pairs_local + FLOP_EPILOGUE * n_local
+    tf = flops / force_avg_s / 1e12 if force_avg_s > 0 else 0.0
+    fp32 = {
+        "kernel": "k_force<fused integrate>", "bound": "valu_fp32", "achieved": tf, "peak": FP32_VALU_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TFLOPS, "flops_per_launch": flops,
+        "model": "SURVEY.md 8(d): 7 per stencil candidate + 45 per in-range pair + 25 per particle; candidates %d, in-range "
+                 "pairs %d" % (cand_local, pairs_local),
+    }
+    return hbm, fp32
+
+
+def run_single(name, steps, warmup, device, evolve=0):
+    """One single-GPU scene: `evolve` untimed steps, `warmup` untimed steps, `steps` timed steps with HIP events around
+    the force kernel, then neighbour statistics.  Returns a dict (and the solver's scene description)."""
+    kind, cols, rows = WORKLOADS[name]
+    params, a = scenes.dam_break(cols, rows) if kind == "dam" else scenes.uniform_box(cols)
+    n = len(a)
+    with Solver(params, n_max=n, device=device) as solver:
+        solver.upload(a)
+        del a
+        if evolve:
+            solver.stepSimulation(nsteps=evolve)
+        solver.stepSimulation(nsteps=warmup)
+        torch.cuda.synchronize()
+        solver.set_profiling_phases(["force"])
+        solver.reset_phase_times()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solver.stepSimulation(nsteps=steps)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        f_ms, f_k = solver.phase_times()["force"]
+        solver.set_profiling(False)
+        solver.computeDensityPressure()
+        pairs = solver.pair_count()
+        counts = solver.neighbor_counts()
+        cand = stencil_candidates(solver, solver.drv)
+        force_avg_s = (f_ms / max(min(f_k, steps), 1)) * 1e-3
+        hbm, fp32 = force_rooflines(n, force_avg_s, pairs, cand)
+        return {
+            "workload": name, "particles": n, "grid": [solver.drv.nx, solver.drv.ny], "steps": steps, "warmup": warmup,
+            "evolved_steps": evolve, "value": n * steps / elapsed, "unit": "particle-updates/s",
+            "ms_per_step": elapsed / steps * 1e3, "mean_neighbors": pairs / max(n, 1),
+            "max_neighbors": int(counts.max()) - 1 if n else 0,
+            "pair_interactions_per_s": 2.0 * pairs * steps / elapsed,
+            "roofline": {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms")},
+            "roofline_valu": {k: fp32[k] for k in ("achieved", "peak", "unit", "frac")},
+        }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +180,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-scenes", action="store_true",
+                    help="N = 1: skip the extra single-GPU scenes (box4m, dam16m, evolved dam1m) reported beside the headline")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = the workload per GPU (default, the driver's contract); strong = the named workload "
                     "split over the GPUs (BASELINE configs[3]: --workload dam16m --scaling strong)")
@@ -205,6 +286,7 @@ def main():
         inner.set_owned_columns(0, drv.nx)  # count over this rank's own particles only (edge pairs are missed)
     inner.computeDensityPressure()
     pairs_local = inner.pair_count()
+    cand_local = stencil_candidates(inner, drv) if world == 1 else 0
     if world > 1:
         t = torch.tensor([pairs_local], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t)
@@ -218,7 +300,6 @@ def main():
         f_ms, f_k = phases["force"]
         # per step, not per launch: a slab step with neighbours runs the pass as two launches (boundary columns, interior)
         force_avg_s = (f_ms / max(min(f_k, args.steps), 1)) * 1e-3
-        achieved = FORCE_BYTES_PER_PARTICLE * n_local / force_avg_s / 1e9 if force_avg_s > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
@@ -235,6 +316,7 @@ def main():
                     "wave_instructions_per_launch": kf.get("SQ_INSTS_VALU"), "source": src}
         except Exception:
             valu = None
+        roof_hbm, roof_fp32 = force_rooflines(n_local, force_avg_s, pairs_local, cand_local, traffic, valu)
         out = {
             "metric": "particle-updates/sec (full SPH step)",
             "value": value,
@@ -258,24 +340,25 @@ def main():
                 "parallelism": parallelism,
                 "semantics": "snapshot (Jacobi) neighbour velocities, as SPH/MPI_sph.cpp",
             },
-            "roofline": {
-                "kernel": "k_force<fused integrate>",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "avg_launch_ms": force_avg_s * 1e3,
-                "algorithmic_bytes_per_launch": FORCE_BYTES_PER_PARTICLE * n_local,
-                "valu": valu,
-                "note": "pair kernels are VALU-bound at ~50 neighbours (no MFMA: irregular gathers); see DESIGN.md",
-            },
+            "roofline": roof_hbm,
+            "roofline_valu": roof_fp32 if world == 1 else None,
             "phases_ms_per_step": {k: v[0] / 5 for k, v in breakdown.items()},
             "pair_interactions_per_s": 2.0 * pairs * args.steps / elapsed,  # density + force passes
             "mean_neighbors": pairs / max(n_total, 1),
             "ups": args.steps / elapsed,
         }
+        if world == 1 and not force_slab and not args.no_extra_scenes:
+            # the other single-GPU scenes of BASELINE.json (configs[2], the scene of configs[3]) and the headline scene
+            # after 1000 untimed steps (collapsed column, cells up to twice their initial population), same run
+            del solver
+            extras = {}
+            for key, wl, st, evo in (("dam1m_evolved", name, args.steps, 1000), ("box4m", "box4m", max(args.steps // 2, 5), 0),
+                                     ("dam16m", "dam16m", max(args.steps // 4, 5), 0)):
+                try:
+                    extras[key] = run_single(wl, st, max(args.warmup, 3), local_rank, evolve=evo)
+                except Exception as e:  # an extra must not take the headline down
+                    extras[key] = {"error": str(e)}
+            out["extra_scenes"] = extras
         if not args.no_cpu_baseline and world == 1:
             base, extra = cpu_baseline(world)
             out["cpu_baseline"] = base

@@ -192,6 +192,8 @@ __device__ __forceinline__ void density_acc_mask(const DevConsts& c, float2 pi, 
     float rx = pi.x - q.x, ry = pi.y - q.y;
     float r2 = rx * rx + ry * ry;
     float t = r2 - c.h2;
+    // (v_max is half rate; a subtract with the clamp output modifier instead made no difference: the loop is bound by
+    // instruction issue, not by VALU cycles)
     float term = fmaxf(-t, 0.0f);
     dens += c.mass * (c.poly6 * term * term * term);  // MASS * poly6(r2, H), sph.cpp:11,49
     m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);  // (m << 1) | sign(t)
@@ -432,6 +434,8 @@ __device__ __forceinline__ void density_entry(const DevConsts& c, const float2* 
             // Four candidates per trip (the row sentinels absorb the overshoot).  The in-range tests are
             // also shifted into one bit mask per 32 candidates, first candidate in the top bit, and
             // stored for the force pass (k_force), which then needs no distance scan of its own.
+            // (Measured dead end: no branch per group -- lanes past their range reading a block of sentinels
+            // instead -- was 7 % slower.)
             const int lo = s_off[3 * r0], hi = s_off[3 * r1 + 3] - PAIR_ROW_PAD;
             int j = lo;
             for (int w = 0; j < hi; w++) {

@@ -3,8 +3,8 @@
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -s KILL 180 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq1 -o p -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline $* > $OUT/pmc_sq1.log 2>&1 || { tail -5 $OUT/pmc_sq1.log; exit 1; }
-timeout -s KILL 180 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32 SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq2 -o p -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline $* > $OUT/pmc_sq2.log 2>&1 || { tail -5 $OUT/pmc_sq2.log; exit 1; }
+timeout -s KILL 180 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq1 -o p -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-scenes $* > $OUT/pmc_sq1.log 2>&1 || { tail -5 $OUT/pmc_sq1.log; exit 1; }
+timeout -s KILL 180 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32 SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq2 -o p -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-scenes $* > $OUT/pmc_sq2.log 2>&1 || { tail -5 $OUT/pmc_sq2.log; exit 1; }
 python3 - <<PY
 import csv,glob,collections
 d=collections.defaultdict(lambda: collections.defaultdict(list))

@@ -8,7 +8,7 @@ TAG=$1; shift
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline $*"
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-extra-scenes $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1 || { echo "trace run failed"; tail -5 "$OUT/trace.log"; exit 1; }
 pass() {  # name, counters
   timeout -s KILL 180 rocprofv3 --pmc $2 --output-format csv -d "$OUT/pmc_$1" -o p -- python3 bench.py $ARGS > "$OUT/pmc_$1.log" 2>&1 || { echo "pmc pass $1 failed"; tail -5 "$OUT/pmc_$1.log"; exit 1; }
