@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None)
+    ap.add_argument("--rebalance-every", type=int, default=50,
+                    help="N > 1: steps between two slab rebalances (0: never); also SPH_BENCH_REBALANCE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-scenes", action="store_true",
                     help="N = 1: skip the extra single-GPU scenes (box4m, dam16m, evolved dam1m) reported beside the headline")
@@ -235,7 +237,9 @@ def main():
         params, n_total, hist_fn, make_local = sharded(total_cols, rows)
         drv = _lib.derive(params)
         solver = make_hip_slab(params, make_local, local_rank, hist=hist_fn(drv))
-        step = lambda k: solver.step(nsteps=k)  # noqa: E731
+        # the dam collapses to the right: slabs are re-balanced (and the halo messages re-sized) every K steps
+        rebalance_every = int(os.environ.get("SPH_BENCH_REBALANCE", str(args.rebalance_every)))
+        step = lambda k: solver.run(k, rebalance_every)  # noqa: E731
         sync = lambda: torch.cuda.synchronize()  # noqa: E731
         barrier = lambda: dist.barrier()  # noqa: E731
         parallelism = "x-slabs x%d, 2-column ghost halo + migration over RCCL" % world
@@ -338,6 +342,8 @@ def main():
                 "particles": n_total,
                 "grid": [drv.nx, drv.ny],
                 "parallelism": parallelism,
+                "rebalance_every": (rebalance_every if (world > 1 or force_slab) else None),
+                "rebalances": (solver.rebalances if (world > 1 or force_slab) else None),
                 "semantics": "snapshot (Jacobi) neighbour velocities, as SPH/MPI_sph.cpp",
             },
             "roofline": roof_hbm,

@@ -69,6 +69,12 @@ def balanced_bounds(hist, world, min_width=MIN_SLAB_COLS, prev=None):
     return b
 
 
+def halo_capacity(hist, margin=2.5, floor=4096):
+    """Records a halo message must hold: the particles of SPHHIP_HALO_COLS columns plus migrants, sized from the
+    fullest column of the (global) histogram with a margin for compression between two rebalances."""
+    return int(max(margin * HALO_COLS * float(np.max(hist)), floor))
+
+
 class HipSlabBackend:
     """The product backend: libsphhip.so on one GPU, exchange messages as torch CUDA tensors.
     A message is an int32 tensor of (cap + 1) x 5 words: row 0 is the header (word 0 = number of
@@ -80,6 +86,13 @@ class HipSlabBackend:
         self.drv = self.solver.drv
         # run the library on torch's current stream so that RCCL ops and kernels are ordered
         self.solver.follow_torch_stream(torch.cuda.current_stream(self.device))
+        self.n_max = int(n_max)
+        self.set_halo_cap(halo_cap)
+
+    def set_halo_cap(self, halo_cap):
+        """(Re)allocates the four fixed-size message buffers: (cap + 1) 20-byte records each.  Sender and receiver
+        must agree on the size, so the capacity is always derived from data every rank holds (the global column
+        histogram)."""
         self.cap = int(halo_cap)
         mk = lambda: torch.zeros((self.cap + 1, 5), dtype=torch.int32, device=self.device)  # noqa: E731
         self.send_l, self.send_r, self.recv_l, self.recv_r = mk(), mk(), mk(), mk()
@@ -153,6 +166,9 @@ class SlabSolver:
         self.stage_cpu = dist.get_backend(group) == "gloo"
         self._ops_cache = {}
         self.overlap = os.environ.get("SPH_SLAB_OVERLAP", "1") != "0"  # exchange overlapped with the interior columns
+        self.last_hist = None
+        self.last_spread = None
+        self.rebalances = 0
         self.set_bounds(bounds)
 
     # -- partition ----------------------------------------------------------------------------
@@ -166,14 +182,34 @@ class SlabSolver:
         self.backend.set_owned(self.c0, self.c1)
 
     def rebalance(self):
-        """Count-balanced boundaries from the global per-column histogram (one small all-reduce)."""
+        """Count-balanced boundaries from the global per-column histogram (one small all-reduce).  The same histogram
+        re-sizes the halo messages: every rank sees the same numbers, so sender and receiver stay in agreement, and
+        a column that has filled up since the last rebalance (the collapsing dam) cannot overflow them -- the
+        capacity only ever grows.  Returns the new boundaries."""
         self.backend.drop_ghosts()
         h = torch.from_numpy(self.backend.column_histogram().astype(np.int64))
         dev = getattr(self.backend, "device", torch.device("cpu"))
         h = h.to(dev)
         dist.all_reduce(h, group=self.group)
-        self.set_bounds(balanced_bounds(h.cpu().numpy(), self.world, prev=self.bounds))
+        hist = h.cpu().numpy()
+        self.last_hist = hist
+        before = self.owned_counts()
+        self.set_bounds(balanced_bounds(hist, self.world, prev=self.bounds))
+        self.last_spread = (before, self.owned_counts())  # particles per rank under the old / the new boundaries
+        set_cap = getattr(self.backend, "set_halo_cap", None)
+        if set_cap is not None:
+            want = halo_capacity(hist)
+            if want > self.backend.cap:
+                set_cap(want)
+                self._ops_cache = {}
+        self.rebalances += 1
         return self.bounds
+
+    def owned_counts(self):
+        """Particles per rank under the current boundaries, from the histogram of the last rebalance (None before)."""
+        if self.last_hist is None:
+            return None
+        return [int(self.last_hist[self.bounds[g]:self.bounds[g + 1]].sum()) for g in range(self.world)]
 
     # -- halo exchange + migration ------------------------------------------------------------
     def _exchange_start(self, left, right, recv_l, recv_r):
@@ -220,6 +256,18 @@ class SlabSolver:
 
     def _peer(self, group_rank):
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
+
+    def run(self, nsteps, rebalance_every=0, mouse=(0.0, 0.0), strength=0.0):
+        """nsteps steps with a rebalance every `rebalance_every` steps (0: never): what a long run of a scene whose
+        mass moves (the collapsing dam) needs -- the slab loads diverge otherwise and the fullest columns outgrow the
+        halo messages.  A rebalance synchronises the host (histogram download + all-reduce)."""
+        done = 0
+        while done < nsteps:
+            k = nsteps - done if rebalance_every <= 0 else min(rebalance_every, nsteps - done)
+            self.step(k, mouse, strength)
+            done += k
+            if rebalance_every > 0 and done < nsteps:
+                self.rebalance()
 
     def step(self, nsteps=1, mouse=(0.0, 0.0), strength=0.0):
         """nsteps steps.  Before the first one the halo is exchanged on its own; between two steps of the
@@ -307,8 +355,10 @@ def make_hip_slab(params, particles_or_fn, device, group=None, hist=None):
         hist = np.bincount(col, minlength=drv.nx)
     bounds = balanced_bounds(hist, world)
     per = int(np.max([np.sum(hist[bounds[g]:bounds[g + 1]]) for g in range(world)]))
-    halo_cap = int(max(2.5 * HALO_COLS * np.max(hist), 4096))  # fixed message size: 2.5x the expected halo
-    n_max = int(per * 1.25) + 4 * halo_cap + 1024
+    halo_cap = halo_capacity(hist)  # fixed message size: 2.5x the fullest halo; re-sized at every rebalance
+    # particle capacity: the balanced share with room for imbalance between two rebalances, plus ghosts and
+    # in-flight messages at a grown halo capacity
+    n_max = int(per * 1.5) + 8 * halo_cap + 1024
     backend = HipSlabBackend(params, n_max, device, halo_cap)
     slab = SlabSolver(backend, params, bounds, group)
     if callable(particles_or_fn):

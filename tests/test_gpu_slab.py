@@ -139,3 +139,66 @@ def test_non_finite_position_on_a_slab(tmp_path):
         assert sum(int(m[2:]) for m in msgs) == len(a)
     else:
         assert any("farther than the halo" in m for m in msgs)
+
+
+def _big_scene(cols):
+    """The dam-break column, already moving to the right at 4 units/s: over 320 steps the fluid crosses ~4 grid
+    columns (8k particles per slab boundary), so the slab loads drift apart between rebalances."""
+    params, a = scenes.dam_break(cols)
+    a["vel"][:, 0] = 4.0
+    return params, a
+
+
+def _big_worker(rank, world, port, out_path, cols, legs, leg_steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from sph_amd.slab import make_hip_slab
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params, a = _big_scene(cols)
+        slab = make_hip_slab(params, a, device=0)
+        spreads = []
+        for leg in range(legs):
+            slab.step(leg_steps)
+            if leg < legs - 1:
+                slab.rebalance()
+                spreads.append(slab.last_spread)
+        slab.check()  # raises if a halo message or the particle capacity overflowed on the way
+        got = slab.gather(len(a))
+        if rank == 0:
+            np.save(out_path, got)
+            np.save(out_path + ".spread.npy", np.array(spreads, dtype=np.int64))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hip_slabs_collapsing_dam_256k(tmp_path):
+    """A slab run of a size that is not a toy: the 262144-particle dam break on 4 ranks (sharing the
+    box's one GPU, messages staged through gloo), 320 steps with 3 rebalances while the column collapses to the
+    right -- bit for bit the single-GPU run and the oracle, no overflow of the (re-sized) halo messages, and every
+    rebalance evens the per-rank particle counts out again."""
+    from sph_amd.solver import Solver
+
+    world, cols, legs, leg_steps = 4, 512, 4, 80
+    out = str(tmp_path / "got.npy")
+    mp.spawn(_big_worker, args=(world, _free_port(), out, cols, legs, leg_steps), nprocs=world, join=True)
+    got = np.load(out)
+    params, a = _big_scene(cols)
+    assert len(a) == 262144
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.stepSimulation(nsteps=legs * leg_steps)
+        single = s.download()
+    assert orc.same_bits(got, single)
+    assert orc.same_bits(got, orc.Oracle().step_cells(params, a.copy(), legs * leg_steps))
+    spreads = np.load(out + ".spread.npy")  # [rebalance][before / after][rank]
+    assert spreads.shape == (legs - 1, 2, world)
+    for before, after in spreads:
+        assert before.sum() == len(a) and after.sum() == len(a)
+        # count-balanced to within one grid column's population (a column holds ~2.1k particles here)
+        assert after.max() - after.min() <= before.max() - before.min() + 1
+        assert after.max() - after.min() <= 0.02 * len(a)
+    assert any((b.max() - b.min()) > (c.max() - c.min()) for b, c in spreads)  # the loads did drift apart
+    print("per-rank particle counts before -> after each rebalance:",
+          [(b.tolist(), c.tolist()) for b, c in spreads])
