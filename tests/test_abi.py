@@ -100,3 +100,20 @@ def test_host_shim_exports_reference_shaped_functions():
                  "hip_integrate(", "hip_stepSimulation(", "hip_cleanupSimulation(", "HIP_main(int)",
                  "HIP_performance_test(int)"):
         assert name in out, name
+
+
+def test_mg_library_exports_every_declared_symbol():
+    """libsph_mg.so (the C++ multi-GPU slab driver) loads without a GPU and exports what include/sph_mg.h declares."""
+    from sph_amd import mg
+
+    M = mg.load()
+    src = open(os.path.join(ROOT, "include", "sph_mg.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(sphmg_[a-z_]+)\s*\(", src)))
+    assert len(syms) == 11
+    for s in syms:
+        assert hasattr(M, s), "libsph_mg.so does not export %s" % s
+    assert set(syms) - {"sphmg_last_error"} == set(mg.SIGNATURES)
+    # argument validation needs no device
+    assert M.sphmg_step(None, 0.0, 0.0, 0.0, 1, 0) != 0 and b"bad argument" in M.sphmg_last_error()
+    assert M.sphmg_rebalance_count(None) == 0
