@@ -6,6 +6,12 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <cstdio>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -64,9 +70,14 @@ struct SphMg {
     SphDerived drv;
     int n = 0, world = 0, cap = 0, rebalances = 0;
     bool have_halo = false;  // the ghosts of the next step are already appended
+    bool threaded = true;         // one host thread per slab enqueues its steps (SPHMG_THREADS=0: one thread drives all slabs)
     bool copy_transport = false;  // messages by hipMemcpyAsync instead of RCCL (slabs sharing a device; SPHMG_TRANSPORT=copy)
     std::vector<Slab> slabs;
     std::vector<int> bounds;
+    // SPHMG_TIMING=1: host time spent enqueuing, per phase, printed to stderr by sphmg_destroy
+    bool timing = false;
+    double host_us[6] = {0, 0, 0, 0, 0, 0};
+    long long timed_steps = 0;
 };
 
 namespace {
@@ -107,6 +118,19 @@ int halo_capacity(const std::vector<long long>& hist) {
     return (int)std::max<long long>((long long)(2.5 * HALO * (double)m), 4096);
 }
 
+struct HostTimer {
+    SphMg* mg;
+    int slot;
+    std::chrono::steady_clock::time_point t0;
+    HostTimer(SphMg* m, int s) : mg(m), slot(s) {
+        if (mg->timing) t0 = std::chrono::steady_clock::now();
+    }
+    ~HostTimer() {
+        if (mg->timing) mg->host_us[slot] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+const char* const HOST_PHASE[6] = {"pack", "exchange", "append", "step_begin", "step_finish", "step"};
+
 int alloc_messages(SphMg* mg, int cap) {
     const size_t bytes = sizeof(HaloRec) * ((size_t)cap + 1);
     for (Slab& s : mg->slabs) {
@@ -136,6 +160,7 @@ int set_bounds(SphMg* mg, const std::vector<int>& b) {
 // communication streams, ordered behind the packs by events; the compute streams wait for `received` before they
 // append.  Replaces MPI_Allgather x 4 per step (MPI_sph.cpp:144-147,163-166).
 int exchange(SphMg* mg) {
+    HostTimer ht(mg, 1);
     const size_t bytes = sizeof(HaloRec) * ((size_t)mg->cap + 1);
     for (Slab& s : mg->slabs) {
         HIP_OK(hipSetDevice(s.device));
@@ -179,6 +204,7 @@ int exchange(SphMg* mg) {
 }
 
 int append_received(SphMg* mg) {
+    HostTimer ht(mg, 2);
     for (int g = 0; g < mg->world; g++) {
         Slab& s = mg->slabs[g];
         HIP_OK(hipSetDevice(s.device));
@@ -191,6 +217,7 @@ int append_received(SphMg* mg) {
 }
 
 int pack_all(SphMg* mg) {
+    HostTimer ht(mg, 0);
     for (int g = 0; g < mg->world; g++) {
         Slab& s = mg->slabs[g];
         const bool has_l = g > 0, has_r = g < mg->world - 1;
@@ -200,6 +227,8 @@ int pack_all(SphMg* mg) {
     return SPHHIP_OK;
 }
 
+int run_steps_threaded(SphMg* mg, float mx, float my, float strength, int k);
+
 // k steps between two rebalances.  Every step but the last is split: the columns next to the slab boundaries first
 // (sphhip_step_begin), then the messages of the NEXT step are packed from them and travel while the interior
 // columns are computed (sphhip_step_finish).
@@ -208,29 +237,201 @@ int run_steps(SphMg* mg, float mx, float my, float strength, int k) {
         SPH_OK(sphhip_step(mg->slabs[0].ctx, mx, my, strength, k));
         return SPHHIP_OK;
     }
+    if (mg->threaded) return run_steps_threaded(mg, mx, my, strength, k);
     for (int i = 0; i < k; i++) {
         if (!mg->have_halo) {
             int rc;
             if ((rc = pack_all(mg)) || (rc = exchange(mg)) || (rc = append_received(mg))) return rc;
         }
         mg->have_halo = false;
+        mg->timed_steps++;
         if (i == k - 1) {
+            HostTimer ht(mg, 5);
             for (Slab& s : mg->slabs) SPH_OK(sphhip_step(s.ctx, mx, my, strength, 1));
             break;
         }
-        for (int g = 0; g < mg->world; g++)
-            SPH_OK(sphhip_step_begin(mg->slabs[g].ctx, mx, my, strength, g > 0 ? SPHHIP_PACK_REACH : 0,
-                                     g < mg->world - 1 ? SPHHIP_PACK_REACH : 0));
+        {
+            HostTimer ht(mg, 3);
+            for (int g = 0; g < mg->world; g++)
+                SPH_OK(sphhip_step_begin(mg->slabs[g].ctx, mx, my, strength, g > 0 ? SPHHIP_PACK_REACH : 0,
+                                         g < mg->world - 1 ? SPHHIP_PACK_REACH : 0));
+        }
         int rc;
         if ((rc = pack_all(mg)) || (rc = exchange(mg))) return rc;
-        for (Slab& s : mg->slabs) SPH_OK(sphhip_step_finish(s.ctx));
+        {
+            HostTimer ht(mg, 4);
+            for (Slab& s : mg->slabs) SPH_OK(sphhip_step_finish(s.ctx));
+        }
         if ((rc = append_received(mg))) return rc;
         mg->have_halo = true;
     }
     return SPHHIP_OK;
 }
 
+// ---- one host thread per slab ---------------------------------------------------------------------------------------
+// Enqueuing a slab step costs the host 60-120 us (profiles/r02_mg_host_overhead.txt): about ten launches, event
+// records / waits and the transport call.  One thread for eight GPUs would make that 0.5-1 ms per step, more than the
+// GPU needs for a step at 1-2 M particles per GPU; with one thread per slab the slabs are enqueued side by side.
+// With RCCL the threads never meet on the host (every thread groups its own send / recv pair; the ranks meet on the
+// devices); the copy transport waits on the neighbours' events, which have to be recorded first: two host barriers
+// per exchange.
+class HostBarrier {
+   public:
+    explicit HostBarrier(int n) : n_(n) {}
+    // false: some thread failed and broke the barrier (nobody waits any more)
+    bool wait() {
+        std::unique_lock<std::mutex> lk(m_);
+        if (broken_) return false;
+        const long gen = gen_;
+        if (++count_ == n_) {
+            count_ = 0;
+            gen_++;
+            cv_.notify_all();
+            return true;
+        }
+        cv_.wait(lk, [&] { return gen_ != gen || broken_; });
+        return !broken_;
+    }
+    void breakup() {
+        std::lock_guard<std::mutex> lk(m_);
+        broken_ = true;
+        cv_.notify_all();
+    }
+
+   private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int n_, count_ = 0;
+    long gen_ = 0;
+    bool broken_ = false;
+};
+
+int slab_pack(SphMg* mg, int g) {
+    Slab& s = mg->slabs[g];
+    const bool has_l = g > 0, has_r = g < mg->world - 1;
+    SPH_OK(sphhip_pack_halo_async(s.ctx, has_l ? s.c0 + HALO : -1, has_r ? s.c1 - HALO : BIG, has_l ? s.send_l : nullptr,
+                                  has_r ? s.send_r : nullptr, mg->cap));
+    return SPHHIP_OK;
+}
+
+// Starts slab g's transfers on its communication stream, ordered behind the pack just enqueued.
+int slab_send(SphMg* mg, int g, HostBarrier& bar) {
+    Slab& s = mg->slabs[g];
+    const size_t bytes = sizeof(HaloRec) * ((size_t)mg->cap + 1);
+    HIP_OK(hipEventRecord(s.packed, s.compute));
+    if (mg->copy_transport) {
+        if (!bar.wait()) return fail(SPHHIP_ESTATE, "another slab failed");  // the neighbours' `packed` are recorded
+        for (int o = std::max(g - 1, 0); o <= std::min(g + 1, mg->world - 1); o++) HIP_OK(hipStreamWaitEvent(s.comm_stream, mg->slabs[o].packed, 0));
+        if (g > 0) HIP_OK(hipMemcpyAsync(mg->slabs[g - 1].recv_r, s.send_l, bytes, hipMemcpyDefault, s.comm_stream));
+        if (g < mg->world - 1) HIP_OK(hipMemcpyAsync(mg->slabs[g + 1].recv_l, s.send_r, bytes, hipMemcpyDefault, s.comm_stream));
+        HIP_OK(hipEventRecord(s.received, s.comm_stream));
+        return SPHHIP_OK;
+    }
+    HIP_OK(hipStreamWaitEvent(s.comm_stream, s.packed, 0));
+    NCCL_OK(ncclGroupStart());
+    if (g > 0) {
+        NCCL_OK(ncclSend(s.send_l, bytes, ncclInt8, g - 1, s.comm, s.comm_stream));
+        NCCL_OK(ncclRecv(s.recv_l, bytes, ncclInt8, g - 1, s.comm, s.comm_stream));
+    }
+    if (g < mg->world - 1) {
+        NCCL_OK(ncclSend(s.send_r, bytes, ncclInt8, g + 1, s.comm, s.comm_stream));
+        NCCL_OK(ncclRecv(s.recv_r, bytes, ncclInt8, g + 1, s.comm, s.comm_stream));
+    }
+    NCCL_OK(ncclGroupEnd());
+    HIP_OK(hipEventRecord(s.received, s.comm_stream));
+    return SPHHIP_OK;
+}
+
+// Makes slab g's compute stream wait for its messages and appends them.
+int slab_receive(SphMg* mg, int g, HostBarrier& bar) {
+    Slab& s = mg->slabs[g];
+    if (mg->copy_transport) {
+        if (!bar.wait()) return fail(SPHHIP_ESTATE, "another slab failed");  // the neighbours' `received` are recorded
+        for (int o = std::max(g - 1, 0); o <= std::min(g + 1, mg->world - 1); o++) HIP_OK(hipStreamWaitEvent(s.compute, mg->slabs[o].received, 0));
+    } else {
+        HIP_OK(hipStreamWaitEvent(s.compute, s.received, 0));
+    }
+    if (g > 0) SPH_OK(sphhip_append_message(s.ctx, s.recv_l, mg->cap));
+    if (g < mg->world - 1) SPH_OK(sphhip_append_message(s.ctx, s.recv_r, mg->cap));
+    return SPHHIP_OK;
+}
+
+// The k steps of run_steps for slab g: per slab the same order of calls as the one-thread loop.
+int slab_steps(SphMg* mg, int g, HostBarrier& bar, float mx, float my, float strength, int k, bool have_halo) {
+    Slab& s = mg->slabs[g];
+    HIP_OK(hipSetDevice(s.device));
+    struct Lap {  // the host time of slab 0's thread stands for all (they run side by side)
+        SphMg* mg;
+        bool on;
+        std::chrono::steady_clock::time_point t;
+        void mark(int slot) {
+            if (!on) return;
+            const auto now = std::chrono::steady_clock::now();
+            mg->host_us[slot] += std::chrono::duration<double, std::micro>(now - t).count();
+            t = now;
+        }
+    } lap{mg, mg->timing && g == 0, std::chrono::steady_clock::now()};
+    int rc;
+    for (int i = 0; i < k; i++) {
+        if (!have_halo) {
+            if ((rc = slab_pack(mg, g))) return rc;
+            lap.mark(0);
+            if ((rc = slab_send(mg, g, bar))) return rc;
+            lap.mark(1);
+            if ((rc = slab_receive(mg, g, bar))) return rc;
+            lap.mark(2);
+        }
+        have_halo = false;
+        if (g == 0) mg->timed_steps++;
+        if (i == k - 1) {
+            SPH_OK(sphhip_step(s.ctx, mx, my, strength, 1));
+            lap.mark(5);
+            break;
+        }
+        SPH_OK(sphhip_step_begin(s.ctx, mx, my, strength, g > 0 ? SPHHIP_PACK_REACH : 0, g < mg->world - 1 ? SPHHIP_PACK_REACH : 0));
+        lap.mark(3);
+        if ((rc = slab_pack(mg, g))) return rc;
+        lap.mark(0);
+        if ((rc = slab_send(mg, g, bar))) return rc;  // travels while the interior columns are computed
+        lap.mark(1);
+        SPH_OK(sphhip_step_finish(s.ctx));
+        lap.mark(4);
+        if ((rc = slab_receive(mg, g, bar))) return rc;
+        lap.mark(2);
+        have_halo = true;
+    }
+    return SPHHIP_OK;
+}
+
+int run_steps_threaded(SphMg* mg, float mx, float my, float strength, int k) {
+    HostBarrier bar(mg->world);
+    std::vector<int> rcs(mg->world, 0);
+    std::vector<std::string> msgs(mg->world);
+    std::vector<std::thread> team;
+    const bool have_halo = mg->have_halo;
+    for (int g = 0; g < mg->world; g++)
+        team.emplace_back([&, g] {
+            rcs[g] = slab_steps(mg, g, bar, mx, my, strength, k, have_halo);
+            if (rcs[g]) {
+                msgs[g] = g_err;  // (thread-local in this thread)
+                bar.breakup();
+            }
+        });
+    for (std::thread& t : team) t.join();
+    mg->have_halo = false;  // the last step of a run is never split
+    for (int g = 0; g < mg->world; g++)
+        if (rcs[g] && msgs[g] != "another slab failed") return fail(rcs[g], "slab " + std::to_string(g) + ": " + msgs[g]);
+    for (int g = 0; g < mg->world; g++)
+        if (rcs[g]) return fail(rcs[g], msgs[g]);
+    return SPHHIP_OK;
+}
+
 void destroy(SphMg* mg) {
+    if (mg->timing && mg->timed_steps > 0) {
+        std::fprintf(stderr, "[sphmg] host enqueue time per step over %lld steps, %d slabs (us):", mg->timed_steps, mg->world);
+        for (int i = 0; i < 6; i++) std::fprintf(stderr, " %s %.1f", HOST_PHASE[i], mg->host_us[i] / (double)mg->timed_steps);
+        std::fprintf(stderr, "\n");
+    }
     for (Slab& s : mg->slabs) {
         (void)hipSetDevice(s.device);
         if (s.ctx) sphhip_destroy(s.ctx);
@@ -269,6 +470,10 @@ extern "C" int sphmg_create(const SphParams* p, const void* aos28, int n, int n_
     mg->params = *p;
     mg->n = n;
     mg->world = n_gpus;
+    const char* tm = std::getenv("SPHMG_TIMING");
+    mg->timing = tm && *tm && std::strcmp(tm, "0");
+    const char* th = std::getenv("SPHMG_THREADS");
+    mg->threaded = !(th && !std::strcmp(th, "0"));
     if (int rc = sphhip_derive(p, &mg->drv)) {
         delete mg;
         return fail(rc, sphhip_last_error());
