@@ -482,6 +482,63 @@ def test_full_size_16m_dam_break_one_step():
     assert orc.same_bits(got, O.step_cells(params, a, 1))
 
 
+def test_full_size_8m_dam_break_one_step():
+    """The per-GPU scene of BASELINE configs[4] (weak scaling, 8M particles per GPU: a 2896 x 2896 dam-break column)
+    on one GPU: one step bit for bit against the cell-list oracle, and -- size-independent -- the ids stay a
+    permutation and every particle stays inside the walls."""
+    params, a = scenes.dam_break(2896)
+    assert len(a) == 2896 * 2896
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.stepSimulation(nsteps=1)
+        got, ids = s.download(with_ids=True)
+    assert np.array_equal(np.sort(ids), np.arange(len(a)))
+    assert got["pos"][:, 0].min() >= params.xmin and got["pos"][:, 0].max() <= params.xmax
+    assert got["pos"][:, 1].min() >= params.ymin and got["pos"][:, 1].max() <= params.ymax
+    assert orc.same_bits(got, O.step_cells(params, a, 1))
+
+
+@pytest.mark.parametrize("kind", ["dam", "box"])
+def test_scaled_scenes_tolerance_vs_serial(kind, capsys):
+    """Density, acceleration and position against the reference's serial semantics (all pairs in index order,
+    in-place velocity update: sph.cpp:41-55,57-100) on miniatures of the bench scenes, after 40 steps of motion.
+    Stated tolerances (fp32): density rel 4e-6 (summation order only); acceleration, relative to the largest
+    acceleration of the scene, 2e-6 against the same sum with snapshot velocities (summation order only) and 5e-4
+    against serial (its viscosity term sees already-updated v_j for j < i); |dx| <= 1e-6 after 5 further steps.
+    Measured (printed by the test): dam 4.2e-7 / 1.6e-7 / 1.3e-4 / 1.6e-7, box 3.2e-7 / 1.6e-7 / 9.8e-5 / 2.4e-7."""
+    params, a = scenes.dam_break(48) if kind == "dam" else scenes.uniform_box(56)
+    a = O.step_cells(params, a.copy(), 40)  # (bit-identical to the HIP path, checked elsewhere)
+    dt = np.float32(params.dt)
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.computeDensityPressure()
+        dens = s.download()
+        s.computeForces()
+        forced = s.download()
+        s.upload(a)
+        s.stepSimulation(nsteps=5)
+        stepped = s.download()
+    ref_d = O.density_allpairs(params, a.copy())
+    d_rel = (np.abs(dens["density"] - ref_d["density"]) / ref_d["density"]).max()
+    acc = (forced["vel"] - dens["vel"]) / dt
+    serial = O.forces_allpairs(params, ref_d.copy(), flags=orc.GAUSS_SEIDEL)
+    snap = O.forces_allpairs(params, ref_d.copy(), flags=orc.SNAPSHOT)
+    acc_serial = (serial["vel"] - ref_d["vel"]) / dt
+    acc_snap = (snap["vel"] - ref_d["vel"]) / dt
+    scale = np.abs(acc_serial).max()
+    a_serial = np.abs(acc - acc_serial).max() / scale
+    a_snap = np.abs(acc - acc_snap).max() / scale
+    ref5 = O.step_allpairs(params, a.copy(), 5, flags=orc.GAUSS_SEIDEL)
+    dx = np.abs(stepped["pos"] - ref5["pos"]).max()
+    with capsys.disabled():
+        print("\n[%s miniature, %d particles] density rel %.2e; acceleration / max|a| (%.3g): vs snapshot sum %.2e, vs serial "
+              "%.2e; |dx| after 5 steps %.2e" % (kind, len(a), d_rel, scale, a_snap, a_serial, dx))
+    assert d_rel <= 4e-6
+    assert a_snap <= 2e-6
+    assert a_serial <= 5e-4
+    assert dx <= 1e-6
+
+
 def test_long_horizon_dam_break_bit_exact():
     """800 steps of a 16k-particle dam break: the column collapses, particles reach MAX_VEL, cells fill up to
     twice their initial population (tiles split, second batches of own particles), the grid is re-sorted 800
