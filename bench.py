@@ -316,7 +316,7 @@ def main():
             src = json.load(open(tf)).get(name, {}).get("source")
             pm = json.load(open(os.path.join(ROOT, src)))
             kf = [v for k, v in pm.items() if k.startswith("k_force<true")][0]
-            valu = {"busy_frac": kf.get("valu_busy_frac"), "lane_utilisation": kf.get("valu_lane_utilisation"),
+            valu = {"cycles_per_wave_instruction": kf.get("valu_cycles_per_wave_instr"), "lane_utilisation": kf.get("valu_lane_utilisation"),
                     "wave_instructions_per_launch": kf.get("SQ_INSTS_VALU"), "source": src}
         except Exception:
             valu = None

@@ -48,7 +48,12 @@ for k, cs in counters.items():
         d["hbm_bytes"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
     if "SQ_ACTIVE_INST_VALU" in d and "SQ_BUSY_CYCLES" in d and d.get("GRBM_GUI_ACTIVE"):
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; 256 CUs x 4 SIMDs issue slots
-        d["valu_busy_frac"] = d["SQ_ACTIVE_INST_VALU"] * 4.0 / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        d["valu_busy_frac"] = min(1.0, d["SQ_ACTIVE_INST_VALU"] * 4.0 / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0))  # (GRBM clock: an upper estimate)
+    if k in kstats and d.get("SQ_INSTS_VALU"):
+        # issue rate: shader cycles (2.1 GHz under this load, s_memtime against s_memrealtime) per VALU wave-instruction
+        # and SIMD (1024 SIMDs).  fp32 fma / mul / add issue every 2 cycles at >= 4 waves, most other VALU ops every
+        # 4, rcp / rsq every 8 (tools/ubench/valu_issue.hip), so 3-3.5 means the VALU pipe is the limiter.
+        d["valu_cycles_per_wave_instr"] = kstats[k]["avg_ns"] * 1e-9 * 2.1e9 * 1024.0 / d["SQ_INSTS_VALU"]
     if "SQ_THREAD_CYCLES_VALU" in d and d.get("SQ_ACTIVE_INST_VALU"):
         d["valu_lane_utilisation"] = d["SQ_THREAD_CYCLES_VALU"] / (d["SQ_ACTIVE_INST_VALU"] * 64.0)
     if k in kstats:
@@ -67,7 +72,7 @@ json.dump(traffic, open(tf, "w"), indent=1, sort_keys=True)
 
 with open(os.path.join("profiles", tag + "_summary.md"), "w") as f:
     f.write("# rocprofv3 summary `%s` (workload %s)\n\n" % (tag, workload))
-    f.write("| kernel | calls | avg us | % | HBM read MB | HBM write MB | VALU busy | lane util | LDS bank conflict/idx |\n|---|---|---|---|---|---|---|---|---|\n")
+    f.write("| kernel | calls | avg us | % | HBM read MB | HBM write MB | cycles / VALU wave-instr | lane util | LDS bank conflict/idx |\n|---|---|---|---|---|---|---|---|---|\n")
     for k, s in sorted(kstats.items(), key=lambda kv: -kv[1]["pct"]):
         d = summary.get(k, {})
         fm = lambda v, sc=1.0, fmt="%.2f": (fmt % (v * sc)) if v is not None else "-"  # noqa: E731
@@ -76,5 +81,5 @@ with open(os.path.join("profiles", tag + "_summary.md"), "w") as f:
             conf = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
         f.write("| %s | %d | %.1f | %.2f | %s | %s | %s | %s | %s |\n" % (
             k, s["calls"], s["avg_ns"] / 1e3, s["pct"], fm(d.get("hbm_read_bytes"), 1e-6), fm(d.get("hbm_write_bytes"), 1e-6),
-            fm(d.get("valu_busy_frac")), fm(d.get("valu_lane_utilisation")), fm(conf)))
+            fm(d.get("valu_cycles_per_wave_instr")), fm(d.get("valu_lane_utilisation")), fm(conf)))
 print(open(os.path.join("profiles", tag + "_summary.md")).read())
