@@ -149,7 +149,7 @@ static hipError_t dmalloc(T** p, size_t count) {
 static void free_all(SphCtx* c) {
     void* ptrs[] = {c->pos, c->vel, c->pos2, c->vel2, c->rho, c->prs, c->rho2, c->prs2, c->idv, c->idv2,
                     c->ncount, c->nmask, c->keys, c->keys2, c->perm, c->perm2, c->ids_sorted, c->cell_buf[0], c->cell_buf[1], c->block_hist,
-                    c->digit_total, c->scan_tmp, c->counters, c->tile_list, c->staging, c->dense_list};
+                    c->digit_total, c->scan_tmp, c->counters, c->tile_list, c->staging, c->dense_list, c->big_list};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int ph = 0; ph < SPHHIP_PH_COUNT; ph++) {
@@ -191,6 +191,8 @@ static void ctx_configure(SphCtx* c, const SphParams& p, const SphDerived& d, in
     if (const char* e = getenv("SPHHIP_USE_MASKS")) c->use_masks = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_GRAPH")) c->graph_off = atoi(e) == 0;
     if (const char* e = getenv("SPHHIP_SMALL_GRID")) c->small_grid = atoi(e) != 0;
+    if (const char* e = getenv("SPHHIP_RANK_BIG")) c->rank_big = atoi(e) != 0;
+    if (c->rank_big && sph_rank_big_setup() != SPHHIP_OK) c->rank_big = false;  // (no 128 KB LDS opt-in: the loop ranks everything)
     if (const char* e = getenv("SPHHIP_DENSE_TP")) c->dense_tp = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_LAZY_PACK")) c->lazy_pack = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_GRID")) c->grid_counting = std::string(e) != "radix";
@@ -234,6 +236,8 @@ static void ctx_buffers(SphCtx* c, bool with_staging, F&& f) {
     c->dense_cap = c->n_max / 4 + 64;
     if (const char* e = getenv("SPHHIP_DENSE_CAP")) c->dense_cap = std::max(1, atoi(e));  // (tests: force an overflow)
     f((void**)&c->dense_list, sizeof(int4) * (size_t)c->dense_cap, false);
+    c->big_cap = c->n_max / RANK_BIG_MIN + 1;  // (no more cells than that can be above RANK_BIG_MIN)
+    f((void**)&c->big_list, sizeof(int) * (size_t)c->big_cap, true);
     if (with_staging) f(&c->staging, std::max<size_t>(n * SPHHIP_PARTICLE_BYTES, 64), false);
 }
 

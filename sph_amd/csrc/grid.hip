@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
                                                        float2* __restrict__ vel_o, float* __restrict__ rho_o,
                                                        float* __restrict__ prs_o, uint32_t* __restrict__ idv_o,
                                                        int head_blocks, int* __restrict__ zero_buf, int zero_words,
-                                                       int* __restrict__ zero_buf2, int zero_words2, int ncell) {
+                                                       int* __restrict__ zero_buf2, int zero_words2, int ncell, int skip_big) {
     if ((int)blockIdx.x < head_blocks) {
         // head workgroups: zero the idle cell table for the next build -- a small launch saved per step.  (The work
         // list of the pair kernels was built here too: its 60 registers per thread cost the latency-bound reorder
@@ -333,6 +333,8 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
     uint32_t k = skeys[s];
     if (k >= (uint32_t)ncell) return;  // (never for a slot below the count; a stale key must not become an address)
     int a = cell_start[k], b = cell_start[k + 1];
+    // a crowded cell is ranked by k_rank_big (sorted ids instead of this loop over all cell-mates)
+    if (skip_big && b - a > RANK_BIG_MIN && b - a <= RANK_BIG_MAX) return;
     uint32_t my = ids_sorted[s];
     int rank = 0;
     for (int t = a; t < b; t++) rank += (ids_sorted[t] < my) ? 1 : 0;
@@ -345,6 +347,81 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
         prs_o[dst] = prs[src];
     }
     idv_o[dst] = idv[src];
+}
+
+// The same ranking for crowded cells.  The loop above reads every cell-mate's id per particle: quadratic in the cell
+// population (a pile-up of 16 k particles in one cell: 0.8 ms, a tenth of that scene's step).  Cells above
+// RANK_BIG_MIN particles are listed by k_scan_apply; here one workgroup per listed cell sorts the cell's ids in LDS
+// (bitonic, padded to a power of two) and every particle finds its rank by binary search.  Same destination slots,
+// bit for bit.  Cells above RANK_BIG_MAX ids (128 KB of LDS) stay with the loop.  Launched only while the host has
+// seen dense sub-tiles (a crowded cell always makes some), so ordinary scenes pay nothing.
+template <bool CARRY_DENSITY>
+__global__ __launch_bounds__(RANK_BIG_THREADS) void k_rank_big(
+    const int* __restrict__ big_list, const int* __restrict__ big_count, int big_cap, const uint32_t* __restrict__ perm,
+    const uint32_t* __restrict__ ids_sorted, const int* __restrict__ cell_start, const float2* __restrict__ pos,
+    const float2* __restrict__ vel, const float* __restrict__ rho, const float* __restrict__ prs,
+    const uint32_t* __restrict__ idv, float2* __restrict__ pos_o, float2* __restrict__ vel_o, float* __restrict__ rho_o,
+    float* __restrict__ prs_o, uint32_t* __restrict__ idv_o) {
+    extern __shared__ uint32_t s_ids[];
+    const int tid = (int)threadIdx.x;
+    const int total = min(*big_count, big_cap);
+    for (int e = (int)blockIdx.x; e < total; e += (int)gridDim.x) {
+        const int k = big_list[e];
+        const int a = cell_start[k], b = cell_start[k + 1];
+        const int np = b - a;
+        if (np <= RANK_BIG_MIN || np > RANK_BIG_MAX) continue;  // (uniform over the workgroup)
+        int m = RANK_BIG_MIN;
+        while (m < np) m <<= 1;
+        __syncthreads();  // the previous cell's searches are done
+        for (int i = tid; i < m; i += RANK_BIG_THREADS) s_ids[i] = i < np ? ids_sorted[a + i] : 0xffffffffu;
+        __syncthreads();
+        for (int size = 2; size <= m; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (m >> 1); t += RANK_BIG_THREADS) {
+                    const int lo = 2 * t - (t & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const uint32_t x = s_ids[lo], y = s_ids[hi];
+                    if ((x > y) == up) {
+                        s_ids[lo] = y;
+                        s_ids[hi] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < np; i += RANK_BIG_THREADS) {
+            const uint32_t my = ids_sorted[a + i];
+            int lo = 0, hi = np;  // ids are unique: the first index whose id is not below mine is my rank
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_ids[mid] < my)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            const int dst = a + lo;
+            const uint32_t src = perm[a + i];
+            pos_o[dst] = pos[src];
+            vel_o[dst] = vel[src];
+            if (CARRY_DENSITY) {
+                rho_o[dst] = rho[src];
+                prs_o[dst] = prs[src];
+            }
+            idv_o[dst] = idv[src];
+        }
+    }
+}
+
+int sph_rank_big_setup() {
+    // 128 KB of dynamic LDS needs the opt-in (64 KB is the default limit)
+    const int bytes = RANK_BIG_MAX * (int)sizeof(uint32_t);
+    if (hipFuncSetAttribute((const void*)k_rank_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_rank_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return SPHHIP_EHIP;
+    }
+    return SPHHIP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -426,7 +503,9 @@ __global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t* __restrict
 
 // Exclusive prefix sum over len ints in place, chunks of SCAN_CHUNK: chunk sums, then every chunk adds
 // the sums of the chunks before it (summed by the workgroup itself: at most a few thousand values).
-__global__ __launch_bounds__(256) void k_scan_reduce(const int* __restrict__ a, int len, int* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_scan_reduce(const int* __restrict__ a, int len, int* __restrict__ part,
+                                                      int* __restrict__ zero_me) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;  // the crowded-cell counter k_scan_apply adds to
     __shared__ int w[4];
     const int base = blockIdx.x * SCAN_CHUNK;
     int sum = 0;
@@ -444,7 +523,8 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const int* __restrict__ a, 
 
 __global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ a, int len, const int* __restrict__ part,
                                                      int* __restrict__ zero_me, int* __restrict__ n_sorted,
-                                                     int* __restrict__ n_out) {
+                                                     int* __restrict__ n_out, int first_cell, int* __restrict__ big_list,
+                                                     int* __restrict__ big_count, int big_cap) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;  // the tile counter of the pair kernels
     __shared__ int buf[SCAN_CHUNK];
     __shared__ int wsum[4];
@@ -469,7 +549,12 @@ __global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ a, int len
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         v[r] = run;
-        run += buf[tid * 8 + r];
+        const int cnt = buf[tid * 8 + r];
+        run += cnt;
+        if (cnt > RANK_BIG_MIN && base + tid * 8 + r < len - 1) {  // crowded cell: ranked by k_rank_big
+            const int e = atomicAdd(big_count, 1);
+            if (e < big_cap) big_list[e] = first_cell + base + tid * 8 + r;
+        }
     }
     int incl = run;
 #pragma unroll
@@ -690,10 +775,11 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             // (the chunk sums are a kernel of their own: accumulating them with atomics in k_cell_count puts
             // thousands of atomics on a few hundred addresses, 0.4 us each -- measured 0.1 ms)
             hipLaunchKernelGGL(k_scan_reduce, dim3(r_parts), dim3(256), 0, st, c->cell_start + r_first, r_len,
-                               c->cell_start + len);
+                               c->cell_start + len, c->counters + SPH_BIG_COUNT_SLOT);
             hipLaunchKernelGGL(k_scan_apply, dim3(r_parts), dim3(256), 0, st, c->cell_start + r_first, r_len, c->cell_start + len,
                                c->counters + SPH_TILE_COUNT_SLOT, c->counters + SPH_N_SORTED_SLOT,
-                               count_update ? sph_n_slot_next(c) : (int*)nullptr);
+                               count_update ? sph_n_slot_next(c) : (int*)nullptr, r_first, c->big_list,
+                               c->counters + SPH_BIG_COUNT_SLOT, c->big_cap);
             LAUNCH_CHECK();
             if (n > 0) {  // (k_scan_apply has zeroed the list's counter)
                 TileListArgs tl = {};
@@ -775,17 +861,34 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             head = std::min(64, (r_len + 2047) / 2048 + 1);
         }
         int* zero_buf = c->cell_buf[1 - c->cell_cur];
+        // crowded cells (listed by this build's k_scan_apply) go to k_rank_big while the host has seen dense sub-tiles
+        // -- a crowded cell always makes some -- or does not know yet; a cell that becomes crowded in between is
+        // ranked by k_rank_reorder's loop for a step: the same result, only slower
+        const bool big = c->grid_counting && !fused && c->rank_big && ((volatile int*)c->h_dense)[0] != 0;
         if (fused) {
             // (k_grid_small has reordered, listed the tiles and zeroed the idle table)
         } else if (carry_density)
             hipLaunchKernelGGL(k_rank_reorder<true>, dim3(nb + head), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
                                c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
-                               c->prs2, c->idv2, head, zero_buf + r_first, r_len, zero_buf + len, r_parts, ncell);
+                               c->prs2, c->idv2, head, zero_buf + r_first, r_len, zero_buf + len, r_parts, ncell, big ? 1 : 0);
         else
             hipLaunchKernelGGL(k_rank_reorder<false>, dim3(nb + head), dim3(256), 0, st, c->keys, c->perm, c->ids_sorted,
                                c->cell_start, c->d_n, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2, c->vel2, c->rho2,
-                               c->prs2, c->idv2, head, zero_buf + r_first, r_len, zero_buf + len, r_parts, ncell);
+                               c->prs2, c->idv2, head, zero_buf + r_first, r_len, zero_buf + len, r_parts, ncell, big ? 1 : 0);
         LAUNCH_CHECK();
+        if (big) {
+            const int blocks = std::min(c->big_cap, 2 * c->num_cus);
+            const size_t lds = sizeof(uint32_t) * RANK_BIG_MAX;
+            if (carry_density)
+                hipLaunchKernelGGL(k_rank_big<true>, dim3(blocks), dim3(RANK_BIG_THREADS), lds, st, c->big_list, c->counters + SPH_BIG_COUNT_SLOT,
+                                   c->big_cap, c->perm, c->ids_sorted, c->cell_start, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
+                                   c->vel2, c->rho2, c->prs2, c->idv2);
+            else
+                hipLaunchKernelGGL(k_rank_big<false>, dim3(blocks), dim3(RANK_BIG_THREADS), lds, st, c->big_list, c->counters + SPH_BIG_COUNT_SLOT,
+                                   c->big_cap, c->perm, c->ids_sorted, c->cell_start, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
+                                   c->vel2, c->rho2, c->prs2, c->idv2);
+            LAUNCH_CHECK();
+        }
         if (head > 0 && range_moved) {  // the head zeroed only the new range of the old table
             HIP_TRY(hipMemsetAsync(zero_buf, 0, sizeof(int) * (size_t)table_words, st));
         }

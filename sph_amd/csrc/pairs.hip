@@ -1086,6 +1086,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
 // in the tuned kernels) goes through the LDS buffer in chunks, one after the other, and every particle
 // walks its part of each chunk: ascending chunks = the canonical order.
 // ---------------------------------------------------------------------------------------------
+// The force sum of a particle at a NaN position is NaN in both components as soon as its stencil holds one other
+// candidate: rx = ry = NaN, so r2 = NaN fails sph.cpp:66's `r2 >= H*H` and every candidate is evaluated, every term
+// being NaN.  (NaNs compare equal in the parity tests whatever their sign or payload: x86 and gfx950 differ there
+// anyway.)  `real` = candidates of the particle's stencil rows, itself included.
+__device__ __forceinline__ bool sph_nan_sum(float2 p, int real) { return (p.x != p.x || p.y != p.y) && real >= 2; }
+
 struct DenseQueue {
     const int4* list;
     const int* count;
@@ -1148,7 +1154,12 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_density_dense(DevConsts c, co
         float dens = 0.0f;
         int cnt = 0;
         const float inf = __builtin_inff();
-        for (int base = 0; base < g.total; base += cap) {
+        // A particle at a NaN position is in range of nothing (r2 = NaN fails sph.cpp:46's `r2 < H*H`): density 0, no
+        // neighbours, whatever the candidates.  Such particles are binned into cell 0 and pile up there once a scene
+        // has blown up (the reference box at N = 65536 holds 38 000 of them after 1000 steps); an entry whose own
+        // particles are all of that kind skips the candidate loop -- 38 000 x 38 000 rejected pairs otherwise.
+        const int total = __syncthreads_or(have && !(pi.x != pi.x || pi.y != pi.y)) ? g.total : 0;
+        for (int base = 0; base < total; base += cap) {
             if (base) __syncthreads();  // the previous chunk has been read
             dense_stage_chunk<THREADS>(
                 g, s_off, base, cap, tix, [&](int dst, int cc, int k) { s_pos[dst] = pos[s_gs[cc] + k]; },
@@ -1204,6 +1215,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_force_dense(
         // exact_div.h only while every density / pressure seen so far is in its safe range (the particle's own
         // record may only arrive with a later chunk, so its operands are checked here)
         int unsafe = allow_fast ? 0 : 1;
+        bool nan_own = false;
         if (valid) {  // sph.cpp:59: invalid particles get no force
             const int cy = (int)own.key - g.col * c.ny;
             const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
@@ -1212,10 +1224,14 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_force_dense(
             hi_seq = s_off[3 * r1 + 3] - PAIR_ROW_PAD;
             self_seq = s_off[self_cell] + (s - s_gs[self_cell]);
             unsafe |= (dens_i == 0.0f || !sph_safe_operand(dens_i) || !sph_safe_operand(pres_i)) ? 1 : 0;
+            nan_own = sph_nan_sum(pi, hi_seq - lo_seq - PAIR_ROW_PAD * (r1 - r0));
         }
         const float inf = __builtin_inff();
         float fx = 0.0f, fy = 0.0f;
-        for (int base = 0; base < g.total; base += chunk_len) {
+        // (see sph_nan_sum: an entry whose particles all sit at NaN positions needs no candidates)
+        const int total = __syncthreads_or(valid && !nan_own) ? g.total : 0;
+        if (total == 0 && nan_own) fx = fy = __builtin_nanf("");
+        for (int base = 0; base < total; base += chunk_len) {
             if (base) __syncthreads();  // the previous chunk has been read
             dense_stage_chunk<THREADS>(
                 g, s_off, base, chunk_len, tix,
@@ -1297,14 +1313,23 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_force_dense_tp(
         const int own0 = g.own_lo + ent.w * DENSE_PART_TP;
         const int n_own = min(DENSE_PART_TP, g.own_hi - own0);
         int unsafe = allow_fast ? 0 : 1;
+        bool live = false;  // a particle whose sum needs the candidates
+        __syncthreads();    // (the table of tile_setup)
         if (tix < n_own) {
-            s_f[tix] = make_float2(0.0f, 0.0f);
-            const float di = rho[own0 + tix], pi_ = prs[own0 + tix];
+            const int s = own0 + tix;
+            const float di = rho[s], pi_ = prs[s];
             unsafe |= (di == 0.0f || !sph_safe_operand(di) || !sph_safe_operand(pi_)) ? 1 : 0;
+            const int cy = (int)skeys[s] - g.col * c.ny;
+            const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
+            const bool nan_own = sph_nan_sum(pos[s], s_off[3 * r1 + 3] - PAIR_ROW_PAD - s_off[3 * r0] - PAIR_ROW_PAD * (r1 - r0));
+            live = !(idv[s] & SPH_INVALID_BIT) && !nan_own;
+            const float f0 = nan_own ? __builtin_nanf("") : 0.0f;
+            s_f[tix] = make_float2(f0, f0);
         }
-        __syncthreads();
+        // (see sph_nan_sum: an entry whose particles all sit at NaN positions needs no candidates)
+        const int total = __syncthreads_or(live) ? g.total : 0;
         const float inf = __builtin_inff();
-        for (int base = 0; base < g.total; base += cap) {
+        for (int base = 0; base < total; base += cap) {
             if (base) __syncthreads();  // the previous chunk has been read
             dense_stage_chunk<THREADS>(
                 g, s_off, base, cap, tix,

@@ -105,6 +105,9 @@ struct SphCtx {
     int* d_host_tiles = nullptr;                 // its device address
     int4* dense_list = nullptr;                  // dense sub-tiles of the running pair kernel (pairs.hip: DenseSink)
     int dense_cap = 0;                           // its capacity in entries
+    int* big_list = nullptr;                     // crowded cells of the current grid build (k_scan_apply -> k_rank_big)
+    int big_cap = 0;
+    bool rank_big = true;                        // SPHHIP_RANK_BIG=0: in-cell ranking always by k_rank_reorder's loop
     int* h_dense = nullptr;                      // mapped host ints: entries of the last dense density / force kernel (-1: unknown)
     int* d_dense = nullptr;                      // their device address
     int dense_force_part = 256;                  // own particles per entry of the last force-pass list
@@ -148,6 +151,7 @@ int sph_hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // ---- phase implementations (each enqueues on ctx->stream and returns) -----------------------
 int sph_grid_build(SphCtx* c, bool carry_density);
+int sph_rank_big_setup();  // grid.hip: LDS opt-in of k_rank_big
 int sph_density_launch(SphCtx* c);
 void sph_adapt_tile_cells(SphCtx* c, int n);  // pairs.hip: tile height for the coming grid build
 int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_integrate, int part = 0, int edge_l = 0,
@@ -469,6 +473,10 @@ constexpr int SPH_TILE_COUNT_SLOT = 56;  // SphCtx::counters[56]: number of list
 constexpr int SPH_N_SORTED_SLOT = 57;    // counters[57]: particle count after the last grid build
 constexpr int SPH_MSG_COUNT_SLOT = 58;   // counters[58..59]: record counts of the halo messages being packed
 constexpr int SPH_DENSE_COUNT_SLOT = 61; // counters[61]: entries of the dense sub-tile list
+constexpr int SPH_BIG_COUNT_SLOT = 62;   // counters[62]: cells listed for k_rank_big (more than RANK_BIG_MIN particles)
+constexpr int RANK_BIG_MIN = 2048;       // cells above this population are ranked by sorting their ids in LDS
+constexpr int RANK_BIG_MAX = 32768;      // ... up to this many ids (128 KB of LDS); beyond: k_rank_reorder's loop
+constexpr int RANK_BIG_THREADS = 1024;
 constexpr int SPH_MSG_TICKET_SLOT = 60;  // counters[60]: finished workgroups of the pack kernel
 
 // ring of device-side particle counts (see ctx.hip)

@@ -539,6 +539,87 @@ def test_scaled_scenes_tolerance_vs_serial(kind, capsys):
     assert dx <= 1e-6
 
 
+def _pile_up(k, seed=5):
+    """The reference box with a 4096-particle lattice and k more particles piled up inside one grid cell, in
+    shuffled index order."""
+    base = scenes.lattice(4096)
+    a = np.zeros(len(base) + k, PARTICLE_DTYPE)
+    a[: len(base)] = base
+    rng = np.random.default_rng(seed)
+    blob = a[len(base):]
+    blob["pos"][:, 0] = (1.0 + 0.1 * rng.random(k)).astype(np.float32)
+    blob["pos"][:, 1] = (1.0 + 0.1 * rng.random(k)).astype(np.float32)
+    blob["density"] = 1000.0
+    blob["valid"] = 1
+    return a[rng.permutation(len(a))].copy()
+
+
+@pytest.mark.parametrize("rank_big", ["1", "0"])
+def test_crowded_cell_pile_up(monkeypatch, rank_big, capsys):
+    """20 000 particles in one cell (a corner pile-up late in a run): the in-cell ranking by id sorts such a cell's
+    ids in LDS (k_rank_big) instead of comparing every particle with every cell-mate; SPHHIP_RANK_BIG=0 keeps the
+    loop.  The sorted order must be the canonical (cell, id) order, one step must equal the oracle bit for bit,
+    and a step must finish within 60 ms (measured: about 9 ms, 0.8 ms less with the sort)."""
+    import time
+
+    monkeypatch.setenv("SPHHIP_RANK_BIG", rank_big)
+    a = _pile_up(20000)
+    with Solver(P, n_max=len(a)) as s:
+        s.upload(a)
+        s.buildNeighbors()
+        keys, order, cs, ce = s.cells()
+        _, oorder, oskeys, ocs = O.build_cells(P, a)
+        assert (ce - cs).max() >= 20000
+        assert np.array_equal(keys, oskeys) and np.array_equal(order, oorder)
+        assert np.array_equal(cs, ocs[:-1]) and np.array_equal(ce, ocs[1:])
+        s.upload(a)
+        s.stepSimulation(nsteps=1)
+        got = s.download()
+        s.synchronize()
+        t0 = time.perf_counter()
+        s.stepSimulation(nsteps=3)
+        s.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+    with capsys.disabled():
+        print("\n[pile-up of 20000 in one cell, SPHHIP_RANK_BIG=%s] %.2f ms/step" % (rank_big, ms))
+    assert ms < 60.0
+    assert orc.same_bits_nan(got, O.step_cells(P, a.copy(), 1))
+
+
+def test_crowded_cell_beyond_the_lds_sort():
+    """40 000 particles in one cell: more ids than k_rank_big sorts in LDS (32768), so the loop ranks that cell
+    while the sort ranks the other crowded one (3000 particles); the order stays canonical."""
+    a = _pile_up(40000, seed=9)
+    rng = np.random.default_rng(13)
+    b = np.zeros(3000, PARTICLE_DTYPE)
+    b["pos"][:, 0] = (0.52 + 0.1 * rng.random(3000)).astype(np.float32)
+    b["pos"][:, 1] = (0.52 + 0.1 * rng.random(3000)).astype(np.float32)
+    b["density"] = 1000.0
+    b["valid"] = 1
+    both = np.zeros(len(a) + len(b), PARTICLE_DTYPE)
+    both[: len(a)] = a
+    both[len(a):] = b
+    with Solver(P, n_max=len(both)) as s:
+        s.upload(both)
+        s.buildNeighbors()
+        keys, order, cs, ce = s.cells()
+    _, oorder, oskeys, ocs = O.build_cells(P, both)
+    pops = np.sort(ce - cs)
+    assert pops[-1] >= 40000 and pops[-2] >= 3000
+    assert np.array_equal(keys, oskeys) and np.array_equal(order, oorder)
+
+
+def test_reference_box_65536():
+    """The reference's own box at its largest harness size (N = 65536, serial_main.cpp:120-147: about 390 particles
+    per cell, about 1200 neighbours each): 3 steps bit for bit."""
+    a = scenes.lattice(65536)
+    with Solver(P, n_max=len(a)) as s:
+        s.upload(a)
+        s.stepSimulation(nsteps=3)
+        got = s.download()
+    assert orc.same_bits(got, O.step_cells(P, a.copy(), 3))
+
+
 def test_long_horizon_dam_break_bit_exact():
     """800 steps of a 16k-particle dam break: the column collapses, particles reach MAX_VEL, cells fill up to
     twice their initial population (tiles split, second batches of own particles), the grid is re-sorted 800
