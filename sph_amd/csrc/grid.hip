@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
     if (k >= (uint32_t)ncell) return;  // (never for a slot below the count; a stale key must not become an address)
     int a = cell_start[k], b = cell_start[k + 1];
     // a crowded cell is ranked by k_rank_big (sorted ids instead of this loop over all cell-mates)
-    if (skip_big && b - a > RANK_BIG_MIN && b - a <= RANK_BIG_MAX) return;
+    if (skip_big && b - a > RANK_BIG_MIN) return;
     uint32_t my = ids_sorted[s];
     int rank = 0;
     for (int t = a; t < b; t++) rank += (ids_sorted[t] < my) ? 1 : 0;
@@ -353,15 +353,16 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
 // population (a pile-up of 16 k particles in one cell: 0.8 ms, a tenth of that scene's step).  Cells above
 // RANK_BIG_MIN particles are listed by k_scan_apply; here one workgroup per listed cell sorts the cell's ids in LDS
 // (bitonic, padded to a power of two) and every particle finds its rank by binary search.  Same destination slots,
-// bit for bit.  Cells above RANK_BIG_MAX ids (128 KB of LDS) stay with the loop.  Launched only while the host has
-// seen dense sub-tiles (a crowded cell always makes some), so ordinary scenes pay nothing.
+// bit for bit.  A cell of more than RANK_BIG_MAX ids (128 KB of LDS) is sorted chunk by chunk, the ranks adding up.
+// Launched only while the host has seen dense sub-tiles (a crowded cell always makes some), so ordinary scenes pay
+// nothing.
 template <bool CARRY_DENSITY>
 __global__ __launch_bounds__(RANK_BIG_THREADS) void k_rank_big(
     const int* __restrict__ big_list, const int* __restrict__ big_count, int big_cap, const uint32_t* __restrict__ perm,
-    const uint32_t* __restrict__ ids_sorted, const int* __restrict__ cell_start, const float2* __restrict__ pos,
-    const float2* __restrict__ vel, const float* __restrict__ rho, const float* __restrict__ prs,
-    const uint32_t* __restrict__ idv, float2* __restrict__ pos_o, float2* __restrict__ vel_o, float* __restrict__ rho_o,
-    float* __restrict__ prs_o, uint32_t* __restrict__ idv_o) {
+    const uint32_t* __restrict__ ids_sorted, const int* __restrict__ cell_start, uint32_t* __restrict__ rank_acc,
+    const float2* __restrict__ pos, const float2* __restrict__ vel, const float* __restrict__ rho,
+    const float* __restrict__ prs, const uint32_t* __restrict__ idv, float2* __restrict__ pos_o, float2* __restrict__ vel_o,
+    float* __restrict__ rho_o, float* __restrict__ prs_o, uint32_t* __restrict__ idv_o) {
     extern __shared__ uint32_t s_ids[];
     const int tid = (int)threadIdx.x;
     const int total = min(*big_count, big_cap);
@@ -369,46 +370,57 @@ __global__ __launch_bounds__(RANK_BIG_THREADS) void k_rank_big(
         const int k = big_list[e];
         const int a = cell_start[k], b = cell_start[k + 1];
         const int np = b - a;
-        if (np <= RANK_BIG_MIN || np > RANK_BIG_MAX) continue;  // (uniform over the workgroup)
-        int m = RANK_BIG_MIN;
-        while (m < np) m <<= 1;
-        __syncthreads();  // the previous cell's searches are done
-        for (int i = tid; i < m; i += RANK_BIG_THREADS) s_ids[i] = i < np ? ids_sorted[a + i] : 0xffffffffu;
-        __syncthreads();
-        for (int size = 2; size <= m; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int t = tid; t < (m >> 1); t += RANK_BIG_THREADS) {
-                    const int lo = 2 * t - (t & (stride - 1));
-                    const int hi = lo + stride;
-                    const bool up = (lo & size) == 0;
-                    const uint32_t x = s_ids[lo], y = s_ids[hi];
-                    if ((x > y) == up) {
-                        s_ids[lo] = y;
-                        s_ids[hi] = x;
+        if (np <= RANK_BIG_MIN) continue;  // (uniform over the workgroup; never: the list holds crowded cells only)
+        // chunks of RANK_BIG_MAX ids: rank = sum over the chunks of the ids below mine (ids are unique), the partial
+        // sums of a cell of more than one chunk in rank_acc (a per-slot scratch array nobody else uses here)
+        for (int c0 = 0; c0 < np; c0 += RANK_BIG_MAX) {
+            const int cs = min(RANK_BIG_MAX, np - c0);
+            int m = RANK_BIG_MIN;
+            while (m < cs) m <<= 1;
+            __syncthreads();  // the previous chunk's searches are done
+            for (int i = tid; i < m; i += RANK_BIG_THREADS) s_ids[i] = i < cs ? ids_sorted[a + c0 + i] : 0xffffffffu;
+            __syncthreads();
+            for (int size = 2; size <= m; size <<= 1) {
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int t = tid; t < (m >> 1); t += RANK_BIG_THREADS) {
+                        const int lo = 2 * t - (t & (stride - 1));
+                        const int hi = lo + stride;
+                        const bool up = (lo & size) == 0;
+                        const uint32_t x = s_ids[lo], y = s_ids[hi];
+                        if ((x > y) == up) {
+                            s_ids[lo] = y;
+                            s_ids[hi] = x;
+                        }
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
-        }
-        for (int i = tid; i < np; i += RANK_BIG_THREADS) {
-            const uint32_t my = ids_sorted[a + i];
-            int lo = 0, hi = np;  // ids are unique: the first index whose id is not below mine is my rank
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_ids[mid] < my)
-                    lo = mid + 1;
-                else
-                    hi = mid;
+            const bool last = c0 + cs >= np;
+            for (int i = tid; i < np; i += RANK_BIG_THREADS) {
+                const uint32_t my = ids_sorted[a + i];
+                int lo = 0, hi = cs;  // the first index whose id is not below mine = the ids of this chunk below mine
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_ids[mid] < my)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                if (c0 > 0) lo += (int)rank_acc[a + i];
+                if (!last) {
+                    rank_acc[a + i] = (uint32_t)lo;
+                    continue;
+                }
+                const int dst = a + lo;
+                const uint32_t src = perm[a + i];
+                pos_o[dst] = pos[src];
+                vel_o[dst] = vel[src];
+                if (CARRY_DENSITY) {
+                    rho_o[dst] = rho[src];
+                    prs_o[dst] = prs[src];
+                }
+                idv_o[dst] = idv[src];
             }
-            const int dst = a + lo;
-            const uint32_t src = perm[a + i];
-            pos_o[dst] = pos[src];
-            vel_o[dst] = vel[src];
-            if (CARRY_DENSITY) {
-                rho_o[dst] = rho[src];
-                prs_o[dst] = prs[src];
-            }
-            idv_o[dst] = idv[src];
         }
     }
 }
@@ -881,11 +893,11 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
             const size_t lds = sizeof(uint32_t) * RANK_BIG_MAX;
             if (carry_density)
                 hipLaunchKernelGGL(k_rank_big<true>, dim3(blocks), dim3(RANK_BIG_THREADS), lds, st, c->big_list, c->counters + SPH_BIG_COUNT_SLOT,
-                                   c->big_cap, c->perm, c->ids_sorted, c->cell_start, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
+                                   c->big_cap, c->perm, c->ids_sorted, c->cell_start, c->keys2, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
                                    c->vel2, c->rho2, c->prs2, c->idv2);
             else
                 hipLaunchKernelGGL(k_rank_big<false>, dim3(blocks), dim3(RANK_BIG_THREADS), lds, st, c->big_list, c->counters + SPH_BIG_COUNT_SLOT,
-                                   c->big_cap, c->perm, c->ids_sorted, c->cell_start, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
+                                   c->big_cap, c->perm, c->ids_sorted, c->cell_start, c->keys2, c->pos, c->vel, c->rho, c->prs, c->idv, c->pos2,
                                    c->vel2, c->rho2, c->prs2, c->idv2);
             LAUNCH_CHECK();
         }

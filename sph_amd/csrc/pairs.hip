@@ -1161,11 +1161,19 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_density_dense(DevConsts c, co
         const int total = __syncthreads_or(have && !(pi.x != pi.x || pi.y != pi.y)) ? g.total : 0;
         for (int base = 0; base < total; base += cap) {
             if (base) __syncthreads();  // the previous chunk has been read
+            int finite = 0;
             dense_stage_chunk<THREADS>(
-                g, s_off, base, cap, tix, [&](int dst, int cc, int k) { s_pos[dst] = pos[s_gs[cc] + k]; },
+                g, s_off, base, cap, tix,
+                [&](int dst, int cc, int k) {
+                    const float2 qj = pos[s_gs[cc] + k];
+                    finite |= (fabsf(qj.x) < inf && fabsf(qj.y) < inf) ? 1 : 0;
+                    s_pos[dst] = qj;
+                },
                 [&](int dst) { s_pos[dst] = make_float2(inf, inf); });
-            __syncthreads();
-            const int k0 = max(lo_seq, base), k1 = min(hi_seq, base + cap);
+            // (a chunk of nothing but particles at NaN / infinite positions -- the pile in cell 0, walked by the few
+            // finite particles of the cells around it -- is in range of nobody: 2 ms of the blown-up reference box)
+            const bool chunk_live = __syncthreads_or(finite);
+            const int k0 = max(lo_seq, base), k1 = chunk_live ? min(hi_seq, base + cap) : 0;
             // eight candidates per trip, loads first: at one or two waves per SIMD the LDS latency is not hidden
             for (int k = k0; k < k1; k += 8) {
                 float2 qv[8];
@@ -1232,7 +1240,6 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_force_dense(
         const int total = __syncthreads_or(valid && !nan_own) ? g.total : 0;
         if (total == 0 && nan_own) fx = fy = __builtin_nanf("");
         for (int base = 0; base < total; base += chunk_len) {
-            if (base) __syncthreads();  // the previous chunk has been read
             dense_stage_chunk<THREADS>(
                 g, s_off, base, chunk_len, tix,
                 [&](int dst, int cc, int k) {
@@ -1270,6 +1277,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_force_dense(
                     force_rounds<THREADS, false, true, DENSE_U, DENSE_Q>(c, s_rec, s_q, w0 - base, w1 - base, self_seq - base, pi, vi,
                                                                          pres_i, fx, fy, tix);
             }
+            // The chunk has been read.  A sum that is NaN in both components stays NaN whatever follows: once that
+            // holds for every particle with candidates left (finite particles next to the NaN pile of cell 0, each
+            // walking its tens of thousands of candidates: 9 ms of the blown-up reference box), the entry is done.
+            if (!__syncthreads_or(valid && hi_seq > base + chunk_len && !(fx != fx && fy != fy))) break;
         }
         if (have) {
             if (valid) {
@@ -1330,7 +1341,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_force_dense_tp(
         const int total = __syncthreads_or(live) ? g.total : 0;
         const float inf = __builtin_inff();
         for (int base = 0; base < total; base += cap) {
-            if (base) __syncthreads();  // the previous chunk has been read
+            int alive = 0;  // a particle of this wave with candidates left and a sum that can still change
             dense_stage_chunk<THREADS>(
                 g, s_off, base, cap, tix,
                 [&](int dst, int cc, int k) {
@@ -1365,8 +1376,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_force_dense_tp(
                 const int r0 = max(cy - 1, 0) - g.ylo, r1 = min(cy + 1, c.ny - 1) - g.ylo;
                 const int self_cell = 3 * (cy - g.ylo) + 1;
                 const int self_seq = s_off[self_cell] + (s - s_gs[self_cell]);
-                const int k0 = max(s_off[3 * r0], base), k1 = min(s_off[3 * r1 + 3] - PAIR_ROW_PAD, base + cap);
+                const int hi_seq = s_off[3 * r1 + 3] - PAIR_ROW_PAD;
+                const int k0 = max(s_off[3 * r0], base), k1 = min(hi_seq, base + cap);
                 float2 f = s_f[o];
+                if (f.x != f.x && f.y != f.y) continue;  // NaN in both components stays NaN (see k_force_dense)
                 for (int kk = k0; kk < k1; kk += 64) {
                     const int k = kk + lane;
                     float tx = 0.0f, ty = 0.0f;
@@ -1399,7 +1412,9 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_force_dense_tp(
                     }
                 }
                 if (lane == 0) s_f[o] = f;
+                alive |= (hi_seq > base + cap && !(f.x != f.x && f.y != f.y)) ? 1 : 0;
             }
+            if (!__syncthreads_or(alive)) break;  // (also: the chunk has been read)
         }
         __syncthreads();
         if (tix < n_own) {

@@ -475,7 +475,7 @@ constexpr int SPH_MSG_COUNT_SLOT = 58;   // counters[58..59]: record counts of t
 constexpr int SPH_DENSE_COUNT_SLOT = 61; // counters[61]: entries of the dense sub-tile list
 constexpr int SPH_BIG_COUNT_SLOT = 62;   // counters[62]: cells listed for k_rank_big (more than RANK_BIG_MIN particles)
 constexpr int RANK_BIG_MIN = 2048;       // cells above this population are ranked by sorting their ids in LDS
-constexpr int RANK_BIG_MAX = 32768;      // ... up to this many ids (128 KB of LDS); beyond: k_rank_reorder's loop
+constexpr int RANK_BIG_MAX = 32768;      // ... in chunks of this many ids (128 KB of LDS)
 constexpr int RANK_BIG_THREADS = 1024;
 constexpr int SPH_MSG_TICKET_SLOT = 60;  // counters[60]: finished workgroups of the pack kernel
 

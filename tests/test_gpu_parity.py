@@ -587,8 +587,9 @@ def test_crowded_cell_pile_up(monkeypatch, rank_big, capsys):
 
 
 def test_crowded_cell_beyond_the_lds_sort():
-    """40 000 particles in one cell: more ids than k_rank_big sorts in LDS (32768), so the loop ranks that cell
-    while the sort ranks the other crowded one (3000 particles); the order stays canonical."""
+    """40 000 particles in one cell: more ids than k_rank_big sorts in LDS at a time (32768), so that cell is ranked
+    in two chunks whose partial ranks add up, next to another crowded cell (3000 particles); the order stays
+    canonical."""
     a = _pile_up(40000, seed=9)
     rng = np.random.default_rng(13)
     b = np.zeros(3000, PARTICLE_DTYPE)
