@@ -798,6 +798,7 @@ int sph_sync_n(SphCtx* c) {
         HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
         if (h[1] & SPH_ERR_CAPACITY) return fail(SPHHIP_ECAPACITY, "a capacity of the context was exceeded during asynchronous steps (particle capacity: particles were dropped; dense sub-tile list: their particles were not updated)");
         if (h[1] & SPH_ERR_HALO_OVERFLOW) return fail(SPHHIP_ECAPACITY, "halo message buffer too small during asynchronous steps (records were dropped)");
+        if (h[1] & SPH_ERR_DEBUG_BOUNDS) return fail(SPHHIP_ESTATE, "an index check of a debugging build failed (SPH_DENSE_DEFER_NOINLINE)");
         if (h[1] & SPH_ERR_OUT_OF_SLAB) return fail(SPHHIP_ESTATE, "particles farther than the halo from the owned columns were found (and dropped) by a grid build");
         return fail(SPHHIP_ECAPACITY, "received halo message with a bad record count");
     }

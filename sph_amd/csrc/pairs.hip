@@ -350,8 +350,39 @@ struct DenseSink {
     int part;        // own particles per entry
 };
 
+#ifdef SPH_DENSE_DEFER_NOINLINE
+// Experiment ("out-of-line dense hand-off"): the append as a real function call with scalar
+// arguments, every index checked before use (a bad one raises SPH_ERR_DEBUG_BOUNDS instead of touching memory).
+__device__ __noinline__ void dense_defer_call(int4* list, int* count, int capacity, int* host_flag, int* err, int defer,
+                                              int part, int col, int cy0, int rows, int own, int nx, int ny) {
+    if (!defer) {
+        *(volatile int*)host_flag = 1;
+        return;
+    }
+    if (part <= 0 || own < 0 || col < 0 || col >= nx || cy0 < 0 || rows <= 0 || cy0 + rows > ny) {
+        atomicOr(err, SPH_ERR_DEBUG_BOUNDS);
+        return;
+    }
+    const int nparts = (own + part - 1) / part;
+    const int e = atomicAdd(count, nparts);
+    if (e < 0) {
+        atomicOr(err, SPH_ERR_DEBUG_BOUNDS);
+    } else if (e + nparts <= capacity) {
+        for (int p = 0; p < nparts; p++) list[e + p] = make_int4(col, cy0, rows, p);
+    } else {
+        atomicOr(err, SPH_ERR_CAPACITY);
+    }
+}
+#endif
+
 // true: the sub-tile went to the list (uniform over the workgroup).
-__device__ __forceinline__ bool dense_defer(const DenseSink& d, const TileGeom& g, int tix) {
+__device__ __forceinline__ bool dense_defer(const DenseSink& d, const TileGeom& g, int tix, int nx = 1 << 30, int ny = 1 << 30) {
+#ifdef SPH_DENSE_DEFER_NOINLINE
+    if (tix == 0)
+        dense_defer_call(d.list, d.count, d.capacity, d.host_flag, d.err, d.defer, d.part, g.col, g.cy0, g.cy1 - g.cy0,
+                         g.own_hi - g.own_lo, nx, ny);
+    return d.defer != 0;
+#endif
     if (tix == 0) {
         if (!d.defer) {
             *(volatile int*)d.host_flag = 1;
@@ -381,7 +412,7 @@ __device__ __forceinline__ void density_entry(const DevConsts& c, const float2* 
                                               int* s_off, int* s_gs, int* s_wave, int tix) {
     TileGeom g = entry_geom(c, d);
     const bool use_lds = (d.info & TILE_DENSE) == 0;
-    if (!use_lds && dense_defer(sink, g, tix)) return;
+    if (!use_lds && dense_defer(sink, g, tix, c.nx, c.ny)) return;
     int g0, g1;
     entry_cells_load(c, cell_start, g, tix, g0, g1);
     float2 pi0 = make_float2(0.0f, 0.0f);
@@ -885,7 +916,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
     }
     TileGeom g = entry_geom(c, d);
     const bool use_lds = (d.info & TILE_DENSE) == 0;
-    if (!use_lds && dense_defer(sink, g, tix)) return;
+    if (!use_lds && dense_defer(sink, g, tix, c.nx, c.ny)) return;
     const float inf = __builtin_inff();
     int* s_flags = s_wave + 7;
     uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_q);

@@ -178,7 +178,7 @@ struct PhaseScope {
 };
 
 // sticky error bits of asynchronous steps (SphCtx::d_err)
-enum { SPH_ERR_HALO_OVERFLOW = 1, SPH_ERR_MSG_BAD = 2, SPH_ERR_CAPACITY = 4, SPH_ERR_OUT_OF_SLAB = 8 };
+enum { SPH_ERR_HALO_OVERFLOW = 1, SPH_ERR_MSG_BAD = 2, SPH_ERR_CAPACITY = 4, SPH_ERR_OUT_OF_SLAB = 8, SPH_ERR_DEBUG_BOUNDS = 16 };
 
 // ---- small device helpers -------------------------------------------------------------------
 __device__ __forceinline__ int sph_lane_id() {
