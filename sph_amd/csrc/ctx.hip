@@ -192,6 +192,7 @@ static void ctx_configure(SphCtx* c, const SphParams& p, const SphDerived& d, in
     if (const char* e = getenv("SPHHIP_GRAPH")) c->graph_off = atoi(e) == 0;
     if (const char* e = getenv("SPHHIP_SMALL_GRID")) c->small_grid = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_RANK_BIG")) c->rank_big = atoi(e) != 0;
+    if (const char* e = getenv("SPHHIP_TILE_LIST_FUSED")) c->tile_list_fused = atoi(e) != 0;
     if (c->rank_big && sph_rank_big_setup() != SPHHIP_OK) c->rank_big = false;  // (no 128 KB LDS opt-in: the loop ranks everything)
     if (const char* e = getenv("SPHHIP_DENSE_TP")) c->dense_tp = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_LAZY_PACK")) c->lazy_pack = atoi(e) != 0;

@@ -501,9 +501,16 @@ __global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t* __restrict
                                                        const uint32_t* __restrict__ idv, const int* __restrict__ d_n,
                                                        const int* __restrict__ cell_start,
                                                        uint32_t* __restrict__ skeys, uint32_t* __restrict__ perm,
-                                                       uint32_t* __restrict__ ids_sorted) {
+                                                       uint32_t* __restrict__ ids_sorted, int head_blocks, int nx, int ny,
+                                                       TileListArgs tl, int* __restrict__ err) {
+    if ((int)blockIdx.x < head_blocks) {
+        // head workgroups: the work list of the pair kernels (needs only the finished cell table, like the scatter) --
+        // a launch of its own took 9 us, twice the launch floor, for 35 k threads
+        sph_tile_list_thread((int)(blockIdx.x * blockDim.x + threadIdx.x), cell_start, nx, ny, tl, err);
+        return;
+    }
     const int n = *d_n;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = ((int)blockIdx.x - head_blocks) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = keys[i];
     if (k == 0xffffffffu) return;  // dropped (k_cell_count)
@@ -793,7 +800,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
                                count_update ? sph_n_slot_next(c) : (int*)nullptr, r_first, c->big_list,
                                c->counters + SPH_BIG_COUNT_SLOT, c->big_cap);
             LAUNCH_CHECK();
-            if (n > 0) {  // (k_scan_apply has zeroed the list's counter)
+            if (n > 0 && !c->tile_list_fused) {  // (k_scan_apply has zeroed the list's counter)
                 TileListArgs tl = {};
                 int lo = 0, hi = 0;
                 sph_tile_list_args(c, tl, lo, hi);
@@ -804,8 +811,14 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
         }
         if (n > 0 && !fused) {
             PhaseScope ps(c, SPHHIP_PH_SORT);
-            hipLaunchKernelGGL(k_cell_scatter, dim3((n + 255) / 256), dim3(256), 0, st, c->keys2, c->perm2, c->idv, c->d_n,
-                               c->cell_start, c->keys, c->perm, c->ids_sorted);
+            TileListArgs tl = {};
+            int lo = 0, hi = 0, head = 0;
+            if (c->tile_list_fused) {
+                sph_tile_list_args(c, tl, lo, hi);
+                head = (tl.nthreads + 255) / 256;
+            }
+            hipLaunchKernelGGL(k_cell_scatter, dim3((n + 255) / 256 + head), dim3(256), 0, st, c->keys2, c->perm2, c->idv, c->d_n,
+                               c->cell_start, c->keys, c->perm, c->ids_sorted, head, c->dc.nx, c->dc.ny, tl, c->d_err);
             LAUNCH_CHECK();
         }
         if (count_update) {  // the scan wrote the count without the dropped particles into the next ring slot

@@ -107,6 +107,7 @@ struct SphCtx {
     int dense_cap = 0;                           // its capacity in entries
     int* big_list = nullptr;                     // crowded cells of the current grid build (k_scan_apply -> k_rank_big)
     int big_cap = 0;
+    bool tile_list_fused = true;                 // the work list is built by head workgroups of k_cell_scatter (SPHHIP_TILE_LIST_FUSED=0: own launch)
     bool rank_big = true;                        // SPHHIP_RANK_BIG=0: in-cell ranking always by k_rank_reorder's loop
     int* h_dense = nullptr;                      // mapped host ints: entries of the last dense density / force kernel (-1: unknown)
     int* d_dense = nullptr;                      // their device address

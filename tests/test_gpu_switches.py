@@ -8,6 +8,7 @@ stand-alone phases -- and on a 2-rank slab run (the switches that touch the halo
   SPHHIP_FAST_DIV=0     hipcc's generic `/` and sqrtf instead of exact_div.h
   SPHHIP_SMALL_GRID=0   never the one-workgroup grid build
   SPHHIP_LAZY_PACK=0    the halo pack always compacts the state
+  SPHHIP_TILE_LIST_FUSED=0  the pair kernels' work list from a launch of its own instead of k_cell_scatter's head workgroups
 """
 import os
 
@@ -25,7 +26,7 @@ O = orc.Oracle()
 P = O.default_params()
 
 SWITCHES = [("SPHHIP_GRID", "radix"), ("SPHHIP_USE_MASKS", "0"), ("SPHHIP_FAST_DIV", "0"), ("SPHHIP_SMALL_GRID", "0"),
-            ("SPHHIP_LAZY_PACK", "0")]
+            ("SPHHIP_LAZY_PACK", "0"), ("SPHHIP_TILE_LIST_FUSED", "0")]
 
 
 def _scenes():
