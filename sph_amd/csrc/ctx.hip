@@ -160,6 +160,9 @@ static void free_all(SphCtx* c) {
     if (c->h_dense) (void)hipHostFree(c->h_dense);
     if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 }
 
 // Everything of a context that is not device memory: constants, geometry, tuning switches (environment).
@@ -193,6 +196,7 @@ static void ctx_configure(SphCtx* c, const SphParams& p, const SphDerived& d, in
     if (const char* e = getenv("SPHHIP_SMALL_GRID")) c->small_grid = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_RANK_BIG")) c->rank_big = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_TILE_LIST_FUSED")) c->tile_list_fused = atoi(e) != 0;
+    if (const char* e = getenv("SPHHIP_SPLIT_CONCURRENT")) c->split_concurrent = atoi(e) != 0;
     if (c->rank_big && sph_rank_big_setup() != SPHHIP_OK) c->rank_big = false;  // (no 128 KB LDS opt-in: the loop ranks everything)
     if (const char* e = getenv("SPHHIP_DENSE_TP")) c->dense_tp = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_LAZY_PACK")) c->lazy_pack = atoi(e) != 0;
@@ -270,6 +274,13 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    {
+        // (Default priority on purpose: with the lowest priority, four slabs sharing one GPU -- sixteen streams on the
+        // four hardware queues of a process -- stopped making progress in tests/test_gpu_mg.py.)
+        ok(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        ok(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
     ctx_buffers(c, true, [&](void** slot, size_t bytes, bool zero) {
         ok(hipMalloc(slot, std::max<size_t>(bytes, 4)));
         if (e == hipSuccess && zero) ok(hipMemset(*slot, 0, std::max<size_t>(bytes, 4)));

@@ -1797,6 +1797,12 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     const bool second = part == 2;
     if (second && !c->split.pending) return SPHHIP_OK;
     if (sph_n_grid(c) == 0) return SPHHIP_OK;
+    if (second && c->split.interior_enqueued) {  // the interior pass is already running beside the boundary pass: join
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->split.interior_enqueued = false;
+        c->split.pending = false;
+        return SPHHIP_OK;
+    }
     PhaseScope ps(c, SPHHIP_PH_FORCE);
     // owned columns plus the halo on each side (ghost tiles pass their particles through); on a slab
     // every particle lies inside that range (sphhip_pack_halo keeps nothing farther out)
@@ -1827,6 +1833,21 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     float2 *pout = second ? c->pos : c->pos2, *vout = second ? c->vel : c->vel2;
     const int lo = second ? il : flo, hi = second ? ih : fhi;
     const int skip_lo = part == 1 ? il : 0, skip_hi = part == 1 ? ih : 0;
+    // Slab step in two halves: the boundary columns' pass is a few hundred workgroups, one tile's latency (20 us) of a
+    // nearly empty GPU.  So the interior pass is started first, on the side stream behind everything enqueued so
+    // far, and the boundary pass runs beside it on the context's stream; sphhip_step_finish only joins.  Same kernels, same tiles, disjoint output slots.  Not while dense
+    // sub-tiles are listed (the two passes would share the list) or phases are being timed.
+    bool beside = false;
+    if (part == 1 && c->split_concurrent && c->side_stream && !sink.defer && !c->profiling) {
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->side_stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
+                           c->cell_start, pout, vout, q, il, ih, 0, 0, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength,
+                           c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink);
+        LAUNCH_CHECK();
+        HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
+        beside = true;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
                        c->cell_start, pout, vout, q, lo, hi, skip_lo, skip_hi, c->pair_cap, c->col_lo, c->col_hi,
                        mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink);
@@ -1850,6 +1871,7 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     }
     if (part == 1) {
         c->split.pending = true;
+        c->split.interior_enqueued = beside;
         c->split.masks_ok = masks_ok;
         c->split.il = il;
         c->split.ih = ih;

@@ -54,6 +54,10 @@ struct SphCtx {
     int* d_err = nullptr;   // device: sticky error bits of asynchronous steps
     int ncell = 0;   // nx * ny
     hipStream_t own_stream = nullptr;
+    // slab steps: the interior force pass runs on this stream beside the boundary columns' pass
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool split_concurrent = true;  // SPHHIP_SPLIT_CONCURRENT=0: the two passes one after the other on the context's stream
     hipStream_t stream = nullptr;
     bool have_state = false;
     bool grid_valid = false;
@@ -126,6 +130,7 @@ struct SphCtx {
         bool pending = false, masks_ok = false;
         int il = 0, ih = 0;  // interior columns
         int edge_l = 0, edge_r = 0;  // owned columns sphhip_step_begin finished on each side
+        bool interior_enqueued = false;  // sphhip_step_begin already started the interior pass on the side stream
         float mx = 0, my = 0, strength = 0;
     } split;
 

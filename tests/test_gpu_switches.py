@@ -63,7 +63,7 @@ def test_switch_keeps_every_bit(monkeypatch, var, val):
 
 
 @pytest.mark.parametrize("var,val", [("SPHHIP_LAZY_PACK", "0"), ("SPHHIP_GRID", "radix"), ("SPHHIP_USE_MASKS", "0"),
-                                     ("SPH_SLAB_OVERLAP", "0")])
+                                     ("SPH_SLAB_OVERLAP", "0"), ("SPHHIP_SPLIT_CONCURRENT", "0")])
 def test_switch_on_two_slabs(monkeypatch, tmp_path, var, val):
     """Two ranks (sharing the box's one GPU, messages staged through gloo), 30 steps with a rebalance, several
     steps per call so that the overlapped step_begin / pack / step_finish path runs: same bits as one GPU."""
