@@ -231,6 +231,9 @@ int sphhip_pack_halo_async(SphCtx* ctx, int send_hi_left, int send_lo_right, voi
 /* Appends the records of a received fixed-size message (header + up to cap records, device
  * memory), reading the count from its header on the device: no host synchronisation. */
 int sphhip_append_message(SphCtx* ctx, const void* d_msg, int cap);
+/* The messages from both neighbours in one launch: a first, b behind it (the same result as two
+ * sphhip_append_message calls in that order); either may be NULL. */
+int sphhip_append_messages(SphCtx* ctx, const void* d_msg_a, const void* d_msg_b, int cap);
 /* Synchronises the stream, returns the particle count (n may be NULL) and reports, as
  * SPHHIP_ECAPACITY, any overflow (halo message buffer, context capacity) that happened in the
  * asynchronous calls since the last synchronisation. */

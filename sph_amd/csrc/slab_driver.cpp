@@ -210,8 +210,7 @@ int append_received(SphMg* mg) {
         HIP_OK(hipSetDevice(s.device));
         // own transfers done (the send buffers are free again) and, for the copy transport, the neighbours' pushes too
         for (int o = std::max(g - 1, 0); o <= std::min(g + 1, mg->world - 1); o++) HIP_OK(hipStreamWaitEvent(s.compute, mg->slabs[o].received, 0));
-        if (g > 0) SPH_OK(sphhip_append_message(s.ctx, s.recv_l, mg->cap));
-        if (g < mg->world - 1) SPH_OK(sphhip_append_message(s.ctx, s.recv_r, mg->cap));
+        SPH_OK(sphhip_append_messages(s.ctx, g > 0 ? s.recv_l : nullptr, g < mg->world - 1 ? s.recv_r : nullptr, mg->cap));
     }
     return SPHHIP_OK;
 }
@@ -351,8 +350,7 @@ int slab_receive(SphMg* mg, int g, HostBarrier& bar) {
     } else {
         HIP_OK(hipStreamWaitEvent(s.compute, s.received, 0));
     }
-    if (g > 0) SPH_OK(sphhip_append_message(s.ctx, s.recv_l, mg->cap));
-    if (g < mg->world - 1) SPH_OK(sphhip_append_message(s.ctx, s.recv_r, mg->cap));
+    SPH_OK(sphhip_append_messages(s.ctx, g > 0 ? s.recv_l : nullptr, g < mg->world - 1 ? s.recv_r : nullptr, mg->cap));
     return SPHHIP_OK;
 }
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     "sphhip_pack_halo": [_vp, _ci, _ci, _vp, _ci, _pi, _vp, _ci, _pi],
     "sphhip_pack_halo_async": [_vp, _ci, _ci, _vp, _vp, _ci],
     "sphhip_append_message": [_vp, _vp, _ci],
+    "sphhip_append_messages": [_vp, _vp, _vp, _ci],
     "sphhip_sync_counts": [_vp, _pi],
     "sphhip_keep_columns": [_vp, _ci, _ci],
     "sphhip_drop_ghosts": [_vp],

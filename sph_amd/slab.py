@@ -111,10 +111,8 @@ class HipSlabBackend:
 
     def finish(self, has_left, has_right):
         """Appends what was received; counts stay on the device (no host synchronisation)."""
-        if has_left:
-            self.solver.append_message(self.recv_l.data_ptr(), self.cap)
-        if has_right:
-            self.solver.append_message(self.recv_r.data_ptr(), self.cap)
+        self.solver.append_messages(self.recv_l.data_ptr() if has_left else None,
+                                    self.recv_r.data_ptr() if has_right else None, self.cap)
 
     def check(self):
         """Synchronises and raises if a halo buffer or the particle capacity overflowed."""

@@ -182,6 +182,10 @@ class Solver:
     def append_message(self, d_msg, cap):
         _lib.check(self.L.sphhip_append_message(self.h, ctypes.c_void_p(d_msg), int(cap)))
 
+    def append_messages(self, d_msg_a, d_msg_b, cap):
+        """Both neighbours' messages in one launch (a first, b behind it); either may be None."""
+        _lib.check(self.L.sphhip_append_messages(self.h, ctypes.c_void_p(d_msg_a), ctypes.c_void_p(d_msg_b), int(cap)))
+
     def sync_counts(self):
         v = ctypes.c_int()
         _lib.check(self.L.sphhip_sync_counts(self.h, ctypes.byref(v)))
