@@ -278,6 +278,11 @@ int sphhip_set_profiling_mask(SphCtx* ctx, unsigned phase_mask);
 /* Sums since the last reset: milliseconds and launches per phase (arrays of SPHHIP_PH_COUNT). */
 int sphhip_get_phase_times(SphCtx* ctx, float* ms, int* launches);
 int sphhip_reset_phase_times(SphCtx* ctx);
+/* What the last pair-kernel launches reported about their work list (after a synchronisation): stats[0] entries of
+ * the list (workgroup-sized tiles), [1] rows of a base tile, [2] entries with a long stencil range (257..448
+ * candidates: handled in place by a second pass over the mask words), [3] / [4] entries of the dense sub-tile
+ * list of the last density / force pass; -1 = not reported yet. */
+int sphhip_get_tile_stats(SphCtx* ctx, int* stats5);
 /* Total in-range pairs (j != i, r2 < h*h) counted by the most recent density pass. */
 int sphhip_get_pair_count(SphCtx* ctx, long long* pairs);
 

@@ -149,7 +149,7 @@ static hipError_t dmalloc(T** p, size_t count) {
 static void free_all(SphCtx* c) {
     void* ptrs[] = {c->pos, c->vel, c->pos2, c->vel2, c->rho, c->prs, c->rho2, c->prs2, c->idv, c->idv2,
                     c->ncount, c->nmask, c->keys, c->keys2, c->perm, c->perm2, c->ids_sorted, c->cell_buf[0], c->cell_buf[1], c->block_hist,
-                    c->digit_total, c->scan_tmp, c->counters, c->tile_list, c->staging, c->dense_list, c->big_list};
+                    c->digit_total, c->scan_tmp, c->counters, c->tile_list, c->staging, c->dense_list, c->big_list, c->nmask_hi};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int ph = 0; ph < SPHHIP_PH_COUNT; ph++) {
@@ -197,6 +197,7 @@ static void ctx_configure(SphCtx* c, const SphParams& p, const SphDerived& d, in
     if (const char* e = getenv("SPHHIP_RANK_BIG")) c->rank_big = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_TILE_LIST_FUSED")) c->tile_list_fused = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_SPLIT_CONCURRENT")) c->split_concurrent = atoi(e) != 0;
+    if (const char* e = getenv("SPHHIP_LONG_TILES")) c->long_mode = atoi(e) != 0 ? 1 : 0;
     if (c->rank_big && sph_rank_big_setup() != SPHHIP_OK) c->rank_big = false;  // (no 128 KB LDS opt-in: the loop ranks everything)
     if (const char* e = getenv("SPHHIP_DENSE_TP")) c->dense_tp = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_LAZY_PACK")) c->lazy_pack = atoi(e) != 0;
@@ -243,6 +244,8 @@ static void ctx_buffers(SphCtx* c, bool with_staging, F&& f) {
     f((void**)&c->dense_list, sizeof(int4) * (size_t)c->dense_cap, false);
     c->big_cap = c->n_max / RANK_BIG_MIN + 1;  // (no more cells than that can be above RANK_BIG_MIN)
     f((void**)&c->big_list, sizeof(int) * (size_t)c->big_cap, true);
+    // mask words 8..13 of long stencil ranges (allocated last: the layout of everything above is as it was without them)
+    f((void**)&c->nmask_hi, sizeof(uint32_t) * n * (PAIR_MASK_WORDS_MAX - 8), false);
     if (with_staging) f(&c->staging, std::max<size_t>(n * SPHHIP_PARTICLE_BYTES, 64), false);
 }
 
@@ -286,10 +289,11 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
         if (e == hipSuccess && zero) ok(hipMemset(*slot, 0, std::max<size_t>(bytes, 4)));
     });
     ctx_wire(c);
-    ok(hipHostMalloc((void**)&c->h_host_tiles, 2 * sizeof(int), hipHostMallocMapped));
+    ok(hipHostMalloc((void**)&c->h_host_tiles, 3 * sizeof(int), hipHostMallocMapped));
     if (e == hipSuccess) {
         c->h_host_tiles[0] = -1;
         c->h_host_tiles[1] = 0;
+        c->h_host_tiles[2] = -1;
         ok(hipHostGetDevicePointer((void**)&c->d_host_tiles, c->h_host_tiles, 0));
     }
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->num_cus = v; }
@@ -570,7 +574,7 @@ static std::vector<uint64_t> step_sig(const SphCtx* c, float mx, float my, float
             (uint64_t)c->pair_threads, (uint64_t)c->grid_valid, (uint64_t)c->counts_valid, (uint64_t)c->slice_valid,
             (uint64_t)c->tiles_valid, (uint64_t)c->cell_next_zeroed, (uint64_t)c->mask_tile_cells, (uint64_t)c->mask_cap,
             (uint64_t)c->tab_clo, (uint64_t)c->tab_chi, (uint64_t)c->use_masks, (uint64_t)c->fast_div,
-            (uint64_t)(dd != 0), (uint64_t)(df != 0), f(mx), f(my), f(strength)};
+            (uint64_t)(dd != 0), (uint64_t)(df != 0), (uint64_t)(c->long_hold > 0 || ((volatile int*)c->h_host_tiles)[2] < 0), f(mx), f(my), f(strength)};
 }
 
 static bool graph_possible(const SphCtx* c) {
@@ -744,6 +748,18 @@ extern "C" int sphhip_get_neighbor_counts(SphCtx* c, int* counts, int n) {
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return (id[a] & SPH_ID_MASK) < (id[b] & SPH_ID_MASK); });
     for (int k = 0; k < n; k++) counts[k] = cnt[order[k]];
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_get_tile_stats(SphCtx* c, int* stats) {
+    if (!c || !stats) return fail(SPHHIP_EINVAL, "sphhip_get_tile_stats: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    stats[0] = ((volatile int*)c->h_host_tiles)[0];
+    stats[1] = ((volatile int*)c->h_host_tiles)[1];
+    stats[2] = ((volatile int*)c->h_host_tiles)[2];
+    stats[3] = ((volatile int*)c->h_dense)[0];
+    stats[4] = ((volatile int*)c->h_dense)[1];
     return SPHHIP_OK;
 }
 
@@ -1310,7 +1326,7 @@ namespace {
 struct StaticSlot {
     unsigned char* ptr = nullptr;  // device address of `scratch` on this GPU (hipGetSymbolAddress), never the symbol itself
     SphCtx ctx;
-    int host_tiles[2] = {-1, 0};   // stand-ins for the mapped host words of a normal context: always "unknown"
+    int host_tiles[3] = {-1, 0, -1};   // stand-ins for the mapped host words of a normal context: always "unknown"
     int host_dense[2] = {-1, -1};
 };
 constexpr int STATIC_MAX_DEVICES = 64;
@@ -1382,6 +1398,7 @@ extern "C" int sphhip_step_static(const SphParams* p, int device, const void* d_
     if (off > STATIC_SCRATCH_BYTES) return fail(SPHHIP_ECAPACITY, "sphhip_step_static: internal layout exceeds the static scratch array");
     ctx_wire(c);
     sl.host_tiles[0] = -1;
+    sl.host_tiles[2] = -1;
     sl.host_tiles[1] = 0;
     sl.host_dense[0] = sl.host_dense[1] = -1;
     c->h_host_tiles = sl.host_tiles;

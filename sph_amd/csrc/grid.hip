@@ -544,7 +544,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(int* __restrict__ a, int len
                                                      int* __restrict__ zero_me, int* __restrict__ n_sorted,
                                                      int* __restrict__ n_out, int first_cell, int* __restrict__ big_list,
                                                      int* __restrict__ big_count, int big_cap) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;  // the tile counter of the pair kernels
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the tile counters of the pair kernels
+        zero_me[0] = 0;
+        zero_me[SPH_LONG_COUNT_OFFSET] = 0;
+    }
     __shared__ int buf[SCAN_CHUNK];
     __shared__ int wsum[4];
     __shared__ int wtot[4];
@@ -626,7 +629,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_grid_small(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = min(*d_n, SMALL_MAX_N);
     for (int k = tid; k <= SMALL_MAX_CELLS; k += SMALL_THREADS) s_start[k] = 0;
-    if (tid == 0) *tile_count = 0;
+    if (tid == 0) {
+        tile_count[0] = 0;
+        tile_count[SPH_LONG_COUNT_OFFSET] = 0;
+    }
     __syncthreads();
     // keys + arrival index within the cell (k_cell_count)
     uint32_t key[4];

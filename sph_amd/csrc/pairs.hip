@@ -230,6 +230,7 @@ __device__ __forceinline__ void for_each_tile(const TileQueue& q, Body&& body) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ((volatile int*)q.host_count)[0] = total;
         ((volatile int*)q.host_count)[1] = q.tile_cells;
+        ((volatile int*)q.host_count)[2] = q.count[SPH_LONG_COUNT_OFFSET];
     }
     while (t < total) {
         const TileDesc d = q.list[t];
@@ -407,7 +408,7 @@ template <int THREADS>
 __device__ __forceinline__ void density_entry(const DevConsts& c, const float2* __restrict__ pos,
                                               const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
                                               float* __restrict__ rho, float* __restrict__ prs,
-                                              int* __restrict__ ncount, uint32_t* __restrict__ nmask, int n_max,
+                                              int* __restrict__ ncount, uint32_t* __restrict__ nmask, uint32_t* __restrict__ nmask_hi, int n_max,
                                               const TileDesc& d, int cap, const DenseSink& sink, float2* s_pos,
                                               int* s_off, int* s_gs, int* s_wave, int tix) {
     TileGeom g = entry_geom(c, d);
@@ -485,7 +486,10 @@ __device__ __forceinline__ void density_entry(const DevConsts& c, const float2* 
                     }
                 }
                 cnt += __popc(m);
-                if (w < PAIR_MASK_WORDS) nmask[(size_t)w * n_max + s] = m;
+                if (w < PAIR_MASK_WORDS)
+                    nmask[(size_t)w * n_max + s] = m;
+                else if (w < PAIR_MASK_WORDS_MAX)  // (long stencil ranges: the words beyond the first 8 have an array of their own)
+                    nmask_hi[(size_t)(w - PAIR_MASK_WORDS) * n_max + s] = m;
             }
         } else {
             for (int cc = 3 * r0; cc < 3 * r1 + 3; cc++) {
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
                                                            const int* __restrict__ cell_start,
                                                            float* __restrict__ rho, float* __restrict__ prs,
                                                            int* __restrict__ ncount, uint32_t* __restrict__ nmask,
-                                                           int n_max, TileQueue q, int col_lo, int col_hi, int cap,
+                                                           uint32_t* __restrict__ nmask_hi, int n_max, TileQueue q, int col_lo, int col_hi, int cap,
                                                            DenseSink sink) {
     extern __shared__ __align__(16) float4 s_dyn[];
     float2* s_pos = reinterpret_cast<float2*>(s_dyn);
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
     int* s_wave = s_gs + PAIR_MAXC;
     for_each_tile(q, [&](const TileDesc& d, int tix, int) {
         if (d.col < col_lo || d.col >= col_hi) return;  // (the list may cover the force pass's wider range)
-        density_entry<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, n_max, d, cap, sink, s_pos, s_off, s_gs,
+        density_entry<THREADS>(c, pos, skeys, cell_start, rho, prs, ncount, nmask, nmask_hi, n_max, d, cap, sink, s_pos, s_off, s_gs,
                                s_wave, tix);
     });
 }
@@ -895,14 +899,14 @@ struct OwnParticle {
 // One list entry of the force pass.  Prologue as in density_entry: the candidate-cell table, the own particles, their
 // mask words (only as many as the entry's longest stencil range needs) and the candidates' records (contiguous
 // slot ranges straight from the entry) are all requested before the first wait; three barriers in all.
-template <bool FUSE, int THREADS>
+template <bool FUSE, int THREADS, bool LONG>
 __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __restrict__ pos,
                                             const float2* __restrict__ vel, const float* __restrict__ rho,
                                             const float* __restrict__ prs, const uint32_t* __restrict__ idv,
                                             const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
                                             float2* __restrict__ pos_o, float2* __restrict__ vel_o, const TileDesc& d,
                                             int cap, int own_lo_col, int own_hi_col, float mx, float my, float strength,
-                                            int allow_fast, const uint32_t* __restrict__ nmask, int n_max,
+                                            int allow_fast, const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ nmask_hi, int n_max,
                                             const DenseSink& sink, PairRec* s_rec, int* s_off, int* s_gs, int* s_wave,
                                             uint8_t* s_q, int tix STAMP_PARAM) {
     STAMP(0);  // entry start
@@ -915,7 +919,13 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
         return;
     }
     TileGeom g = entry_geom(c, d);
-    const bool use_lds = (d.info & TILE_DENSE) == 0;
+    // a "long" tile (some stencil range above FORCE_MAX_RANGE records) needs the masks: two passes over their words
+    // (LONG = false: the kernel the host launches while the list holds no long tile; one that turns up takes the way of the
+    // dense sub-tiles.  Handling them costs this kernel a few scalar registers too many: 3-5 % at 16 M particles.)
+    const int nw_all = d.info & 0xff;
+    const bool long_tile = nw_all > PAIR_MASK_WORDS;
+    const bool long_here = LONG && long_tile;
+    bool use_lds = (d.info & TILE_DENSE) == 0 && !(long_tile && (!LONG || !nmask));
     if (!use_lds && dense_defer(sink, g, tix, c.nx, c.ny)) return;
     const float inf = __builtin_inff();
     int* s_flags = s_wave + 7;
@@ -927,7 +937,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
     OwnParticle own0;
     const bool have0 = g.own_lo + tix < g.own_hi;
     own0.load(g.own_lo + tix, have0, pos, vel, rho, prs, idv, skeys);
-    const int nw_tile = d.info & 0xff;
+    const int nw_tile = min(nw_all, PAIR_MASK_WORDS);
     uint32_t mw[PAIR_MASK_WORDS];
 #pragma unroll
     for (int k = 0; k < PAIR_MASK_WORDS; k++) {
@@ -1010,6 +1020,12 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
         const int all = *s_flags;
         fast = (all & 1) == 0;
         by_mask = fast && (all & 2) == 0;
+        if (long_here && !by_mask) {
+            // the masks cannot be used after all (an operand outside the safe range, an invalid or non-finite candidate)
+            // and the scan path's byte queue does not reach beyond FORCE_MAX_RANGE: the way of the dense sub-tiles
+            if (dense_defer(sink, g, tix, c.nx, c.ny)) return;
+            use_lds = false;
+        }
     }
     STAMP(2);  // staged
     STAMP_VAL(5, (unsigned long long)(g.own_hi - g.own_lo) | ((unsigned long long)s_off[g.ncells] << 32));
@@ -1041,10 +1057,18 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
                 hi = s_off[3 * r1 + 3] - PAIR_ROW_PAD;
                 self = s_off[self_cell] + (s - s_gs[self_cell]);
             }
-            if (by_mask)
-                force_by_mask<THREADS>(c, s_rec, s_mask, (const uint32_t*)nullptr, n_max, j, (hi - j + 31) >> 5, self, pi, vi,
-                                       pres_i, fx, fy, tix);
-            else if (fast)
+            if (by_mask) {
+                // A long tile takes two passes: the candidates beyond the first 8 mask words follow with their words
+                // fetched from global memory (ascending candidates, the same order; lanes whose range is shorter
+                // evaluate themselves meanwhile: terms of +0).  One loop, so that the pop loop exists once in the code.
+                const int nw_i = (hi - j + 31) >> 5;
+                const int npass = long_here ? 2 : 1;
+#pragma nounroll
+                for (int pass = 0; pass < npass; pass++)
+                    force_by_mask<THREADS>(c, s_rec, s_mask, pass ? nmask_hi + s : (const uint32_t*)nullptr,
+                                           n_max, j + pass * FORCE_MAX_RANGE, min(max(nw_i - pass * PAIR_MASK_WORDS, 0), PAIR_MASK_WORDS),
+                                           self, pi, vi, pres_i, fx, fy, tix);
+            } else if (fast)
                 force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
             else
                 force_rounds<THREADS, false>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
@@ -1080,13 +1104,14 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
     STAMP_VAL(6, __builtin_amdgcn_s_memrealtime());
 }
 
-template <bool FUSE, int THREADS>
+template <bool FUSE, int THREADS, bool LONG>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_WAVES_MAX, FORCE_WAVES_MAX))) void k_force(
     DevConsts c, const float2* __restrict__ pos, const float2* __restrict__ vel, const float* __restrict__ rho,
     const float* __restrict__ prs, const uint32_t* __restrict__ idv, const uint32_t* __restrict__ skeys,
     const int* __restrict__ cell_start, float2* __restrict__ pos_o, float2* __restrict__ vel_o, TileQueue q, int col_lo,
     int col_hi, int skip_lo, int skip_hi, int cap, int own_lo_col, int own_hi_col, float mx, float my,
-    float strength, int allow_fast, const uint32_t* __restrict__ nmask, int n_max, DenseSink sink) {
+    float strength, int allow_fast, const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ nmask_hi, int n_max,
+    DenseSink sink) {
     extern __shared__ __align__(16) float4 s_dyn[];
     PairRec* s_rec = reinterpret_cast<PairRec*>(s_dyn);
     int* s_off = reinterpret_cast<int*>(s_rec + cap);
@@ -1105,8 +1130,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
         // columns [col_lo, col_hi) without [skip_lo, skip_hi): a slab step runs the columns next to the slab
         // boundaries first and the interior in a second launch (sph_force_launch)
         if (d.col < col_lo || d.col >= col_hi || (d.col >= skip_lo && d.col < skip_hi)) return;
-        force_entry<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, d, cap, own_lo_col,
-                                   own_hi_col, mx, my, strength, allow_fast, nmask, n_max, sink, s_rec, s_off, s_gs, s_wave,
+        force_entry<FUSE, THREADS, LONG>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, d, cap, own_lo_col,
+                                   own_hi_col, mx, my, strength, allow_fast, nmask, nmask_hi, n_max, sink, s_rec, s_off, s_gs, s_wave,
                                    s_q, tix STAMP_ARG);
     });
 }
@@ -1650,6 +1675,7 @@ static int ensure_tile_list(SphCtx* c, TileQueue& q) {
     sph_tile_list_args(c, tl, lo, hi);
     if (!sph_tiles_current(c, lo, hi)) {
         HIP_TRY(hipMemsetAsync(tl.count, 0, sizeof(int), c->stream));
+        HIP_TRY(hipMemsetAsync(tl.count + SPH_LONG_COUNT_OFFSET, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_tile_list, dim3((tl.nthreads + 255) / 256), dim3(256), 0, c->stream, c->cell_start, c->dc.nx,
                            c->dc.ny, tl, c->d_err);
         LAUNCH_CHECK();
@@ -1775,7 +1801,7 @@ int sph_density_launch(SphCtx* c) {
     bool tp = false;
     if ((rc = dense_prepare(c, 0, sink, dq, dense_grid, tp))) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, c->pos, c->keys, c->cell_start, c->rho,
-                       c->prs, c->ncount, c->nmask, c->n_max, q, lo, hi, c->pair_cap, sink);
+                       c->prs, c->ncount, c->nmask, c->nmask_hi, c->n_max, q, lo, hi, c->pair_cap, sink);
     LAUNCH_CHECK();
     if (sink.defer) {
         hipLaunchKernelGGL(k_density_dense, dim3(dense_grid), dim3(DENSE_THREADS), pair_lds_bytes(c->pair_cap, false, DENSE_THREADS),
@@ -1819,8 +1845,22 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     const bool masks_ok = second ? c->split.masks_ok
                                  : c->use_masks && c->counts_valid && c->grid_valid && c->mask_tile_cells == c->tile_cells &&
                                        c->mask_cap == c->pair_cap;
-    auto kern = fuse_integrate ? (th == 128 ? k_force<true, 128> : k_force<true, 256>)
-                               : (th == 128 ? k_force<false, 128> : k_force<false, 256>);
+    // long tiles (stencil ranges of 257..448 records) are handled in place only by the LONG instantiation, launched while
+    // the list holds any (going by what the last launch reported; -1 = not known yet)
+    // (with hysteresis: the count flickers between 0 and 1 in a scene that has just reached that density, and a long tile
+    // met by the other instantiation costs a dense follow-up launch)
+    const int long_seen = ((volatile int*)c->h_host_tiles)[2];  // (-1: no launch has reported yet)
+    if (!second) {
+        if (long_seen > 0)
+            c->long_hold = 64;
+        else if (c->long_hold > 0)
+            c->long_hold--;
+    }
+    const bool lng = second ? c->split.long_kernel : (c->long_mode < 0 ? (long_seen < 0 || c->long_hold > 0) : c->long_mode != 0);
+    auto kern = lng ? (fuse_integrate ? (th == 128 ? k_force<true, 128, true> : k_force<true, 256, true>)
+                                      : (th == 128 ? k_force<false, 128, true> : k_force<false, 256, true>))
+                    : (fuse_integrate ? (th == 128 ? k_force<true, 128, false> : k_force<true, 256, false>)
+                                      : (th == 128 ? k_force<false, 128, false> : k_force<false, 256, false>));
     int grid = 0;
     if ((rc = pair_grid(c, reinterpret_cast<const void*>(kern), th, lds, grid))) return rc;
     DenseSink sink;
@@ -1843,14 +1883,14 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
         HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->side_stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
                            c->cell_start, pout, vout, q, il, ih, 0, 0, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength,
-                           c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink);
+                           c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->nmask_hi, c->n_max, sink);
         LAUNCH_CHECK();
         HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
         beside = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
                        c->cell_start, pout, vout, q, lo, hi, skip_lo, skip_hi, c->pair_cap, c->col_lo, c->col_hi,
-                       mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink);
+                       mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->nmask_hi, c->n_max, sink);
     LAUNCH_CHECK();
     if (sink.defer) {
         auto dkern = tp ? (fuse_integrate ? k_force_dense_tp<true> : k_force_dense_tp<false>)
@@ -1872,6 +1912,7 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     if (part == 1) {
         c->split.pending = true;
         c->split.interior_enqueued = beside;
+        c->split.long_kernel = lng;
         c->split.masks_ok = masks_ok;
         c->split.il = il;
         c->split.ih = ih;

@@ -81,6 +81,7 @@ struct SphCtx {
     uint32_t *idv = nullptr, *idv2 = nullptr;
     int* ncount = nullptr;  // neighbour counts of the last density pass (slot order)
     uint32_t* nmask = nullptr;  // in-range bit masks of the last density pass: word w of slot s at [w * n_max + s]
+    uint32_t* nmask_hi = nullptr;  // words 8..13 per particle (long stencil ranges), same word-major layout
     int mask_tile_cells = 0, mask_cap = 0;  // tiling the masks were built with
     bool grid_counting = true;  // counting sort by cell (SPHHIP_GRID=radix: the LSD radix sort)
     bool small_grid = true;     // SPHHIP_SMALL_GRID=0: never the one-workgroup grid build (grid.hip: k_grid_small)
@@ -105,12 +106,14 @@ struct SphCtx {
     bool tiles_valid = false;                    // ... current for this grid, tiles_cells, [tiles_lo, tiles_hi)
     int tiles_cells = 0, tiles_lo = 0, tiles_hi = 0, tiles_cap = 0, tiles_threads = 0;
     int num_cus = 256;
-    int* h_host_tiles = nullptr;                 // mapped host ints: tile count of a recent launch (-1: none yet), its tile_cells
+    int* h_host_tiles = nullptr;                 // mapped host ints: tile count of a recent launch (-1: none yet), its tile_cells, long entries (-1: unknown)
     int* d_host_tiles = nullptr;                 // its device address
     int4* dense_list = nullptr;                  // dense sub-tiles of the running pair kernel (pairs.hip: DenseSink)
     int dense_cap = 0;                           // its capacity in entries
     int* big_list = nullptr;                     // crowded cells of the current grid build (k_scan_apply -> k_rank_big)
     int big_cap = 0;
+    int long_hold = 0;                           // force launches left with the LONG instantiation after the last report of long tiles
+    int long_mode = -1;                          // SPHHIP_LONG_TILES=0 / 1: never / always the LONG instantiation (-1: by the reports)
     bool tile_list_fused = true;                 // the work list is built by head workgroups of k_cell_scatter (SPHHIP_TILE_LIST_FUSED=0: own launch)
     bool rank_big = true;                        // SPHHIP_RANK_BIG=0: in-cell ranking always by k_rank_reorder's loop
     int* h_dense = nullptr;                      // mapped host ints: entries of the last dense density / force kernel (-1: unknown)
@@ -130,6 +133,7 @@ struct SphCtx {
         bool pending = false, masks_ok = false;
         int il = 0, ih = 0;  // interior columns
         int edge_l = 0, edge_r = 0;  // owned columns sphhip_step_begin finished on each side
+        bool long_kernel = false;        // the force kernel instantiation of the first half (the second uses the same)
         bool interior_enqueued = false;  // sphhip_step_begin already started the interior pass on the side stream
         float mx = 0, my = 0, strength = 0;
     } split;
@@ -205,7 +209,12 @@ __device__ __forceinline__ int sph_cell_coord(float x, float x0, float inv_cell,
 }
 
 constexpr int PAIR_ROW_PAD = 3;       // sentinel records behind every candidate row of a tile's LDS image (pairs.hip)
-constexpr int FORCE_MAX_RANGE = 256;  // longest 3x3 stencil range (LDS records) of the LDS path: 8 mask words / byte queue
+constexpr int FORCE_MAX_RANGE = 256;  // stencil range (LDS records) one pass of the force kernels handles: 8 mask words / byte queue
+// Longest 3x3 stencil range of the LDS path: 14 mask words per particle.  A tile whose longest range is above
+// FORCE_MAX_RANGE ("long": 29-48 particles per cell) is walked by k_force in two passes over the mask words; without
+// usable masks it goes the way of the dense sub-tiles.  (14, not 16: the list builder packs the word count in 4 bits.)
+constexpr int FORCE_LONG_RANGE = 448;
+constexpr int PAIR_MASK_WORDS_MAX = FORCE_LONG_RANGE / 32;
 
 // ---- tile list of the pair kernels ----------------------------------------------------------------
 // One entry = one workgroup's work: the particles of rows [cy0, cy1) of grid column `col` (one contiguous slot
@@ -214,19 +223,20 @@ constexpr int FORCE_MAX_RANGE = 256;  // longest 3x3 stencil range (LDS records)
 // entry, so the loads of the particle data do not wait for a round trip through the cell table first.
 struct __align__(16) TileDesc {
     int col, cy0, cy1;
-    int info;            // bits 0..7: mask words the longest stencil range of the tile needs; bit 8: dense (see below)
+    int info;            // bits 0..7: mask words the longest stencil range of the tile needs (<= PAIR_MASK_WORDS_MAX); bit 8: dense (see below)
     int own_lo, own_hi;  // slots of the own particles
     int c_lo[3], c_hi[3];  // slots of the candidates in columns col-1, col, col+1 (empty outside the grid)
 };
 static_assert(sizeof(TileDesc) == 48, "TileDesc");
 constexpr int TILE_DENSE = 1 << 8;
+constexpr int SPH_LONG_COUNT_OFFSET = 7;  // the count of long entries sits 7 ints behind the entry count (counters[63])
 constexpr int TILE_FAST_ROWS = 16;  // base tiles up to this height are checked with one batch of loads (sph_tile_list_thread)
 
 // The list is built on the device right after the cell table (tail of the grid build).  Thread i looks at one BASE
 // tile -- `tile_cells` rows of one column, column-major order -- and cuts it into entries such that every entry
 //   * holds at most `max_own` own particles (one lane each, a single pass over the workgroup),
 //   * stages at most `cap` LDS records (candidates + PAIR_ROW_PAD sentinels per row),
-//   * has no stencil range longer than FORCE_MAX_RANGE,
+//   * has no stencil range longer than FORCE_LONG_RANGE,
 // skipping rows without particles at its ends; a single row that violates one of these becomes an entry of its own
 // with TILE_DENSE set (the dense sub-tile kernels take those).  Base tiles that fit as a whole -- the normal case,
 // the host adapts `tile_cells` to the scene -- give one entry.  A wave appends its entries with one atomic.
@@ -286,7 +296,7 @@ struct TileCut {
     __device__ __forceinline__ void row(int y, int prev_cand, int cur_own, int cur_cand, int next_cand, int cap, int max_own,
                                         Emit&& emit) {
         const int len = prev_cand + cur_cand + next_cand - PAIR_ROW_PAD;  // stencil range of the particles of row y
-        const bool row_fits = cur_own <= max_own && prev_cand + cur_cand + next_cand <= cap && len <= FORCE_MAX_RANGE;
+        const bool row_fits = cur_own <= max_own && prev_cand + cur_cand + next_cand <= cap && len <= FORCE_LONG_RANGE;
         if (cur_own > 0) {
             // can row y join the entry [a, last]?  (rows between last and y are empty but are staged as well)
             if (a >= 0 && (!row_fits || own + cur_own > max_own || total + cur_cand + next_cand > cap)) {
@@ -356,6 +366,7 @@ __device__ __forceinline__ void sph_tile_list_thread(int i, const int* __restric
     const int trow = i % tl.tiles_per_col, col = tl.col0 + i / tl.tiles_per_col;
     int k = 0, cy0 = 0, cy1 = 0;
     TileDesc first;
+    int nlong = 0;                           // entries with a stencil range above FORCE_MAX_RANGE (not dense)
     unsigned cut_starts = 0, cut_ends = 0;  // a cut base tile (fast path): first / last row of every entry
     unsigned long long cut_info = 0;        // ... 4 bits per first row: mask words, 15 = dense
     if (i < tl.nthreads && col < tl.col0 + tl.ncols) {
@@ -396,12 +407,13 @@ __device__ __forceinline__ void sph_tile_list_thread(int i, const int* __restric
             walk = false;
             if (own == 0) {
                 // empty base tile: no entry
-            } else if (!(own <= tl.max_own && total <= tl.cap && maxlen <= FORCE_MAX_RANGE)) {
+            } else if (!(own <= tl.max_own && total <= tl.cap && maxlen <= FORCE_LONG_RANGE)) {
                 // to be cut: the cuts are noted in bit masks over the tile's rows (written out below)
                 k = sph_tile_walk_regs<TILE_FAST_ROWS>(own_r, cand, rows, cy0, tl.cap, tl.max_own, [&](int a, int e, int info) {
                     cut_starts |= 1u << (a - cy0);
                     cut_ends |= 1u << (e - 1 - cy0);
                     cut_info |= (unsigned long long)((info & TILE_DENSE) ? 15 : info) << (4 * (a - cy0));
+                    nlong += (!(info & TILE_DENSE) && info > FORCE_MAX_RANGE / 32) ? 1 : 0;
                 });
             } else {
                 k = 1;
@@ -409,6 +421,7 @@ __device__ __forceinline__ void sph_tile_list_thread(int i, const int* __restric
                 first.cy0 = cy0;
                 first.cy1 = cy1;
                 first.info = (maxlen + 31) >> 5;
+                nlong = first.info > FORCE_MAX_RANGE / 32 ? 1 : 0;
                 first.own_lo = b[1][1];
                 int own_hi = 0, hi0 = 0, hi1 = 0, hi2 = 0;
 #pragma unroll
@@ -435,6 +448,7 @@ __device__ __forceinline__ void sph_tile_list_thread(int i, const int* __restric
             k = sph_tile_walk(cell_start, nx, ny, col, cy0, cy1, tl.cap, tl.max_own, [&](int a, int b, int info) {
                 if (!have_first) first = sph_tile_desc(cell_start, nx, ny, col, a, b, info);
                 have_first = true;
+                nlong += (!(info & TILE_DENSE) && info > FORCE_MAX_RANGE / 32) ? 1 : 0;
             });
         }
     }
@@ -451,6 +465,8 @@ __device__ __forceinline__ void sph_tile_list_thread(int i, const int* __restric
     if (lane == 63 && wave_total) base = atomicAdd(tl.count, wave_total);
     base = __shfl(base, 63, 64) + incl - k;
     if (k == 0) return;
+    // (how many entries are "long": the host picks the force kernel that handles them in place only while there are any)
+    if (nlong) atomicAdd(tl.count + SPH_LONG_COUNT_OFFSET, nlong);
     if (base + k > tl.list_cap) {  // (cannot happen: the list holds an entry per particle)
         atomicOr(err, SPH_ERR_CAPACITY);
         return;
@@ -475,7 +491,7 @@ __device__ __forceinline__ void sph_tile_list_thread(int i, const int* __restric
 }
 
 
-constexpr int SPH_TILE_COUNT_SLOT = 56;  // SphCtx::counters[56]: number of listed tiles
+constexpr int SPH_TILE_COUNT_SLOT = 56;  // SphCtx::counters[56]: number of listed tiles (counters[63]: the long ones among them)
 constexpr int SPH_N_SORTED_SLOT = 57;    // counters[57]: particle count after the last grid build
 constexpr int SPH_MSG_COUNT_SLOT = 58;   // counters[58..59]: record counts of the halo messages being packed
 constexpr int SPH_DENSE_COUNT_SLOT = 61; // counters[61]: entries of the dense sub-tile list

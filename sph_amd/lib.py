@@ -59,6 +59,7 @@ SIGNATURES = {
     "sphhip_get_phase_times": [_vp, _vp, _vp],
     "sphhip_reset_phase_times": [_vp],
     "sphhip_get_pair_count": [_vp, ctypes.POINTER(ctypes.c_longlong)],
+    "sphhip_get_tile_stats": [_vp, _pi],
 }
 
 

@@ -114,6 +114,12 @@ class Solver:
         _lib.check(self.L.sphhip_get_neighbor_counts(self.h, _ptr(c), n))
         return c
 
+    def tile_stats(self):
+        """-> dict: work-list entries, rows per base tile, long entries, dense entries (density, force) of the last launches."""
+        st = (ctypes.c_int * 5)()
+        _lib.check(self.L.sphhip_get_tile_stats(self.h, st))
+        return dict(zip(("tiles", "tile_rows", "long", "dense_density", "dense_force"), [int(x) for x in st]))
+
     def pair_count(self):
         v = ctypes.c_longlong()
         _lib.check(self.L.sphhip_get_pair_count(self.h, ctypes.byref(v)))

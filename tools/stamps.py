@@ -15,7 +15,7 @@ from sph_amd import lib as _lib, scenes  # noqa: E402
 from sph_amd.solver import Solver  # noqa: E402
 
 cols = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6  # (e.g. 1000: the evolved scene)
 params, a = scenes.dam_break(cols)
 L = _lib.load()
 L.sphhip_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -51,3 +51,17 @@ print("launch: last tile start at %.1f us, last end at %.1f us" % (start_us.max(
 hist, edges = np.histogram(start_us, bins=12)
 print("tile starts per %.1f-us bin:" % (edges[1] - edges[0]), hist.tolist())
 print("mean tile length %.0f cycles = %.1f us, p90 %.0f" % (whole.mean(), (real[ok] / 100.0).mean(), np.percentile(whole, 90)))
+# concurrency over time: tiles in flight per 5-us bin (1024 = every workgroup slot of the GPU busy at 4 per CU)
+edges = np.arange(0.0, end_us.max() + 5.0, 5.0)
+infl = [(int(((start_us < e1) & (end_us > e0)).sum())) for e0, e1 in zip(edges[:-1], edges[1:])]
+print("tiles in flight per 5-us bin:", infl)
+busy = np.clip(np.minimum(end_us[:, None], edges[None, 1:]) - np.maximum(start_us[:, None], edges[None, :-1]), 0, None).sum(0) / 5.0
+print("mean tiles resident per 5-us bin:", [int(x) for x in busy])
+print("sum of tile lengths / 1024 slots = %.1f us" % ((end_us - start_us).sum() / 1024.0))
+# per XCD (contiguous eighths of the list): tiles, sum of tile lengths, time of the last end
+idx = np.nonzero(used)[0]
+per = (idx.max() + 8) // 8
+for x in range(8):
+    m = (idx // per) == x
+    print("XCD %d: %4d tiles, own particles %7d, sum of tile lengths %7.0f us, first start %5.1f, last end %6.1f us" % (
+        x, m.sum(), own[m].sum(), (end_us[m] - start_us[m]).sum(), start_us[m].min(), end_us[m].max()))
