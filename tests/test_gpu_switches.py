@@ -26,13 +26,15 @@ O = orc.Oracle()
 P = O.default_params()
 
 SWITCHES = [("SPHHIP_GRID", "radix"), ("SPHHIP_USE_MASKS", "0"), ("SPHHIP_FAST_DIV", "0"), ("SPHHIP_SMALL_GRID", "0"),
-            ("SPHHIP_LAZY_PACK", "0"), ("SPHHIP_TILE_LIST_FUSED", "0")]
+            ("SPHHIP_LAZY_PACK", "0"), ("SPHHIP_TILE_LIST_FUSED", "0"), ("SPHHIP_LONG_TILES", "0"), ("SPHHIP_LONG_TILES", "1")]
 
 
 def _scenes():
     g5 = np.load(os.path.join(orc.GOLDEN, "f5_dense_block.npz"), allow_pickle=False)["state"]
     dam_p, dam = scenes.dam_break(48)
-    return [("lattice4096", P, scenes.lattice(4096)), ("f5_dense", P, g5.copy()), ("dam48", dam_p, dam)]
+    # lattice6000: about 35 particles per cell of the reference box, stencil ranges of 257..448 candidates ("long" tiles)
+    return [("lattice4096", P, scenes.lattice(4096)), ("lattice6000", P, scenes.lattice(6000)), ("f5_dense", P, g5.copy()),
+            ("dam48", dam_p, dam)]
 
 
 @pytest.mark.parametrize("var,val", SWITCHES)
