@@ -272,7 +272,9 @@ class SlabSolver:
         same call the exchange overlaps the step: the backend first finishes the columns next to the slab
         boundaries (step_begin), the messages are packed from them and sent while the interior columns
         are computed (step_finish).  The state at return is that after a whole step, as if every step had
-        been exchange, append, step."""
+        been exchange, append, step.  (The last step of a call is deliberately not split: a split step hands its
+        migrants on at once, as 20-byte records without density / pressure, and a download right after the call
+        must still find every particle's density with its owner.)"""
         has_l, has_r = self.rank > 0, self.rank < self.world - 1
         send_hi_left = self.c0 + HALO_COLS if has_l else -1
         send_lo_right = self.c1 - HALO_COLS if has_r else BIG
