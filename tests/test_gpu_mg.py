@@ -99,3 +99,38 @@ def test_sph_main_methods(tmp_path):
     assert open(d1, "rb").read() == open(d2, "rb").read()
     bad = subprocess.run([exe, "--method", "cuda"], capture_output=True, text=True)
     assert bad.returncode == 2
+
+
+def test_transport_selection(monkeypatch):
+    """SPHMG_TRANSPORT: RCCL needs one device per slab (refused when slabs share a device); `copy` is accepted; anything
+    else is an error."""
+    from sph_amd import lib
+    from sph_amd.mg import MultiGpuSolver
+
+    params, a = _scene()
+    monkeypatch.setenv("SPHMG_TRANSPORT", "rccl")
+    with pytest.raises(lib.SphHipError):
+        MultiGpuSolver(params, a, devices=[0, 0])
+    monkeypatch.setenv("SPHMG_TRANSPORT", "bogus")
+    with pytest.raises(lib.SphHipError):
+        MultiGpuSolver(params, a, devices=[0, 0])
+    monkeypatch.setenv("SPHMG_TRANSPORT", "copy")
+    with MultiGpuSolver(params, a, devices=[0, 0]) as m:
+        m.step(3)
+        got = m.download()
+    assert orc.same_bits(got, _single(params, a, 3))
+
+
+def test_dam_scene_of_the_dispatcher_equals_the_python_scene(tmp_path):
+    """sph_main --scene dam builds the dam-break lattice in C++ (sph_main.cpp): same bits as sph_amd.scenes.dam_break,
+    checked through a 2-step run of both methods against the oracle."""
+    exe = os.path.join(ROOT, "sph_amd", "sph_main")
+    params, a = scenes.dam_break(64)
+    want = orc.Oracle().step_cells(params, a.copy(), 2)
+    for method in ("hip", "hip-mg"):
+        dump = str(tmp_path / (method + ".bin"))
+        r = subprocess.run([exe, "--method", method, "--scene", "dam", "--n", "4096", "--mode", "run", "--steps", "2", "--dump", dump],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        got = np.fromfile(dump, dtype=a.dtype)
+        assert orc.same_bits(got, want), method

@@ -676,3 +676,23 @@ def test_error_behaviour():
             s.stepSimulation(nsteps=-1)
         s.stepSimulation(nsteps=2)  # still usable
         assert orc.same_bits(s.download(), O.step_cells(P, a.copy(), 2))
+
+
+def test_tile_stats_and_long_tiles():
+    """sphhip_get_tile_stats: the pristine dam-break miniature has neither long nor dense entries; the reference box at
+    6000 particles (about 35 per cell: stencil ranges of 257..448 candidates) has long entries and no dense ones in the
+    force pass, and steps bit-exactly through the two-pass mask walk."""
+    params, a = scenes.dam_break(64)
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.stepSimulation(nsteps=3)
+        st = s.tile_stats()
+    assert st["tiles"] > 0 and st["long"] == 0 and st["dense_force"] == 0
+    a = scenes.lattice(6000)
+    with Solver(P, n_max=len(a)) as s:
+        s.upload(a)
+        s.stepSimulation(nsteps=4)
+        got = s.download()
+        st = s.tile_stats()
+    assert st["long"] > 0 and st["dense_force"] == 0, st
+    assert orc.same_bits(got, O.step_cells(P, a.copy(), 4))
