@@ -162,6 +162,8 @@ static void free_all(SphCtx* c) {
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : c->ev_pace)
+        if (e) (void)hipEventDestroy(e);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 }
 
@@ -282,6 +284,8 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
         // four hardware queues of a process -- stopped making progress in tests/test_gpu_mg.py.)
         ok(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
         ok(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&c->ev_pace[0], hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&c->ev_pace[1], hipEventDisableTiming));
         ok(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
     ctx_buffers(c, true, [&](void** slot, size_t bytes, bool zero) {
@@ -542,8 +546,32 @@ extern "C" int sphhip_integrate(SphCtx* c) {
     return sph_integrate_launch(c);
 }
 
+// The host enqueues a step in ~20 us, the GPU needs ten times as long: a call of a thousand steps would be enqueued in
+// full while the GPU is still at step 100 -- and everything the host decides from what the kernels report back through
+// mapped memory (grid sizes, tile height, whether the dense follow-up kernels and the long-tile force kernel run) would
+// be decided on news that is 900 steps old (measured: the evolved dam break ran 6 % slower inside one long call than
+// in calls of ten steps).  So every THROTTLE_STEPS steps the host waits until the GPU has passed the mark set
+// THROTTLE_STEPS steps earlier: it stays 32 to 64 steps ahead, never idle-making.  (Not under stream capture, and not
+// for the static context, which has no events.)
+constexpr int THROTTLE_STEPS = 32;
+static int sph_throttle(SphCtx* c) {
+    if (!c->ev_pace[0] || (++c->pace_steps % THROTTLE_STEPS) != 0) return SPHHIP_OK;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (c->stream && (hipStreamIsCapturing(c->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone)) {
+        (void)hipGetLastError();
+        return SPHHIP_OK;
+    }
+    const int cur = (int)((c->pace_steps / THROTTLE_STEPS) & 1);
+    if (c->pace_armed[1 - cur]) HIP_TRY(hipEventSynchronize(c->ev_pace[1 - cur]));
+    HIP_TRY(hipEventRecord(c->ev_pace[cur], c->stream));
+    c->pace_armed[cur] = true;
+    return SPHHIP_OK;
+}
+
 static int step_once(SphCtx* c, float mx, float my, float strength) {
-    int rc = sph_grid_build(c, false);
+    int rc = sph_throttle(c);
+    if (rc) return rc;
+    rc = sph_grid_build(c, false);
     if (rc) return rc;
     rc = sph_density_launch(c);
     if (rc) return rc;
@@ -671,7 +699,9 @@ extern "C" int sphhip_step(SphCtx* c, float mx, float my, float strength, int ns
 extern "C" int sphhip_step_begin(SphCtx* c, float mx, float my, float strength, int edge_left, int edge_right) {
     NEED_STATE(c);
     if (edge_left < 0 || edge_right < 0) return fail(SPHHIP_EINVAL, "sphhip_step_begin: negative edge width");
-    int rc = sph_grid_build(c, false);
+    int rc = sph_throttle(c);
+    if (rc) return rc;
+    rc = sph_grid_build(c, false);
     if (rc) return rc;
     rc = sph_density_launch(c);
     if (rc) return rc;

@@ -57,6 +57,10 @@ struct SphCtx {
     // slab steps: the interior force pass runs on this stream beside the boundary columns' pass
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Bound on how far the host runs ahead of the GPU (sph_throttle): an event every THROTTLE_STEPS steps, two in rotation
+    hipEvent_t ev_pace[2] = {nullptr, nullptr};
+    long pace_steps = 0;
+    bool pace_armed[2] = {false, false};
     bool split_concurrent = true;  // SPHHIP_SPLIT_CONCURRENT=0: the two passes one after the other on the context's stream
     hipStream_t stream = nullptr;
     bool have_state = false;
