@@ -1277,9 +1277,23 @@ extern "C" int sphhip_sync_counts(SphCtx* c, int* n) {
 
 __global__ __launch_bounds__(256) void k_col_hist(DevConsts c, int n, const float2* __restrict__ pos,
                                                    int* __restrict__ hist) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    atomicAdd(&hist[sph_cell_coord(pos[i].x, c.xmin, c.inv_cell, c.nx)], 1);
+    // The state is in (or near) cell order, and the cell keys are column-major: the 64 particles of a wave sit in one or
+    // two columns.  One atomic per run of equal columns in a wave (as k_cell_count does for cells) instead of one per
+    // particle -- 4000 serialised atomics per column address made a rebalance of 1 M particles take 1.9 ms.
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < n;
+    const int col = ok ? sph_cell_coord(pos[i].x, c.xmin, c.inv_cell, c.nx) : -1;
+    const int lane = sph_lane_id();
+    const int prev = __shfl_up(col, 1, 64);
+    const bool head = ok && (lane == 0 || prev != col);
+    const unsigned long long heads = __ballot(head);
+    const int n_ok = __popcll(__ballot(ok));  // the in-range lanes are a prefix of the wave
+    if (head) {
+        const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+        const unsigned long long above = heads & ~upto;
+        const int next = above ? __ffsll((long long)above) - 1 : n_ok;
+        atomicAdd(&hist[col], next - lane);
+    }
 }
 
 extern "C" int sphhip_column_histogram(SphCtx* c, int* hist) {
