@@ -179,7 +179,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None)
-    ap.add_argument("--rebalance-every", type=int, default=50,
+    ap.add_argument("--rebalance-every", type=int, default=100,
                     help="N > 1: steps between two slab rebalances (0: never); also SPH_BENCH_REBALANCE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-scenes", action="store_true",
