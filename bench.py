@@ -34,6 +34,9 @@ from sph_amd.solver import Solver  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X peak FP32 vector (MI355X_MICROARCH.md)
+# HIP events around k_force in one step of this many inside the timed region: an event pair leaves ~11 us of gaps on the
+# stream (rocprofv3 kernel trace), i.e. bracketing every step would slow the measured loop itself by 4-5 %
+FORCE_SAMPLE_PERIOD = 8
 FORCE_BYTES_PER_PARTICLE = 40  # fused force + integrate, SURVEY.md 8(d)
 # algorithmic flops, SURVEY.md 8(d): per stencil candidate 7 (2 sub, 2 mul, add, cmp, select), per in-range density
 # pair +6, per in-range force pair +45 (div and sqrt counted as 1 each), per particle epilogue ~25
@@ -148,6 +151,7 @@ def run_single(name, steps, warmup, device, evolve=0):
         solver.stepSimulation(nsteps=warmup)
         torch.cuda.synchronize()
         solver.set_profiling_phases(["force"])
+        solver.set_profiling_period(FORCE_SAMPLE_PERIOD)
         solver.reset_phase_times()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -160,7 +164,7 @@ def run_single(name, steps, warmup, device, evolve=0):
         pairs = solver.pair_count()
         counts = solver.neighbor_counts()
         cand = stencil_candidates(solver, solver.drv)
-        force_avg_s = (f_ms / max(min(f_k, steps), 1)) * 1e-3
+        force_avg_s = (f_ms / max(f_k, 1)) * 1e-3  # (f_k: the sampled launches)
         hbm, fp32 = force_rooflines(n, force_avg_s, pairs, cand)
         return {
             "workload": name, "particles": n, "grid": [solver.drv.nx, solver.drv.ny], "steps": steps, "warmup": warmup,
@@ -254,6 +258,7 @@ def main():
     # events would time the boundary pass only; the slab line takes the kernel time from the breakdown steps below)
     if not slabbed:
         inner.set_profiling_phases(["force"])
+        inner.set_profiling_period(FORCE_SAMPLE_PERIOD)
     inner.reset_phase_times()
     barrier()
     sync()
@@ -266,6 +271,7 @@ def main():
     phases = inner.phase_times()
     inner.set_profiling(False)
     # per-phase breakdown: a few extra steps with every phase bracketed (not part of `value`)
+    inner.set_profiling_period(1)
     inner.set_profiling(True)
     inner.reset_phase_times()
     step(5)
@@ -308,7 +314,8 @@ def main():
         value = n_total * args.steps / elapsed
         f_ms, f_k = phases["force"]
         # per step, not per launch: a slab step with neighbours runs the pass as two launches (boundary columns, interior)
-        force_avg_s = (f_ms / max(min(f_k, 5 if slabbed else args.steps), 1)) * 1e-3  # (slabs: the 5 breakdown steps)
+        # single GPU: the sampled launches of the timed region; slabs: per step over the 5 breakdown steps (two launches each)
+        force_avg_s = (f_ms / max(min(f_k, 5) if slabbed else f_k, 1)) * 1e-3
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):

@@ -25,8 +25,12 @@ static int fail(int code, const char* msg) {
 }
 
 // ---- phase timing ---------------------------------------------------------------------------
+static inline bool phase_timed(const SphCtx* c, int ph) {
+    return c->profiling && ((c->profile_mask >> ph) & 1u) && (c->profile_period <= 1 || c->profile_step == 0 || (c->profile_step - 1) % c->profile_period == 0);  // steps 1, 1 + period, ...
+}
+
 void sph_phase_begin(SphCtx* c, int ph) {
-    if (!c->profiling || !((c->profile_mask >> ph) & 1u)) return;
+    if (!phase_timed(c, ph)) return;
     PhaseTimer& t = c->timer;
     if (t.used[ph] == t.start[ph].size()) {
         hipEvent_t a, b;
@@ -38,7 +42,7 @@ void sph_phase_begin(SphCtx* c, int ph) {
 }
 
 void sph_phase_end(SphCtx* c, int ph) {
-    if (!c->profiling || !((c->profile_mask >> ph) & 1u)) return;
+    if (!phase_timed(c, ph)) return;
     PhaseTimer& t = c->timer;
     if (t.used[ph] >= t.stop[ph].size()) return;
     (void)hipEventRecord(t.stop[ph][t.used[ph]], c->stream);
@@ -569,6 +573,7 @@ static int sph_throttle(SphCtx* c) {
 }
 
 static int step_once(SphCtx* c, float mx, float my, float strength) {
+    c->profile_step++;
     int rc = sph_throttle(c);
     if (rc) return rc;
     rc = sph_grid_build(c, false);
@@ -699,6 +704,7 @@ extern "C" int sphhip_step(SphCtx* c, float mx, float my, float strength, int ns
 extern "C" int sphhip_step_begin(SphCtx* c, float mx, float my, float strength, int edge_left, int edge_right) {
     NEED_STATE(c);
     if (edge_left < 0 || edge_right < 0) return fail(SPHHIP_EINVAL, "sphhip_step_begin: negative edge width");
+    c->profile_step++;
     int rc = sph_throttle(c);
     if (rc) return rc;
     rc = sph_grid_build(c, false);
@@ -1324,6 +1330,14 @@ extern "C" int sphhip_set_profiling(SphCtx* c, int enable) {
     timer_flush(c);
     c->profiling = enable != 0;
     c->profile_mask = ~0u;
+    return SPHHIP_OK;
+}
+
+extern "C" int sphhip_set_profiling_period(SphCtx* c, int period) {
+    if (!c) return fail(SPHHIP_EINVAL, "null context");
+    if (period < 1) return fail(SPHHIP_EINVAL, "sphhip_set_profiling_period: period < 1");
+    c->profile_period = period;
+    c->profile_step = 0;
     return SPHHIP_OK;
 }
 

@@ -144,6 +144,8 @@ struct SphCtx {
 
     bool profiling = false;
     unsigned profile_mask = ~0u;  // bit ph: bracket that phase with events
+    int profile_period = 1;       // ... in every profile_period-th step only (an event pair costs the stream ~11 us of gaps)
+    long profile_step = 0;        // steps begun since profiling was last configured
     PhaseTimer timer;
 };
 

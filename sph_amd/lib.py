@@ -56,6 +56,7 @@ SIGNATURES = {
     "sphhip_selftest_division": [_ci, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)],
     "sphhip_set_profiling": [_vp, _ci],
     "sphhip_set_profiling_mask": [_vp, ctypes.c_uint],
+    "sphhip_set_profiling_period": [_vp, _ci],
     "sphhip_get_phase_times": [_vp, _vp, _vp],
     "sphhip_reset_phase_times": [_vp],
     "sphhip_get_pair_count": [_vp, ctypes.POINTER(ctypes.c_longlong)],

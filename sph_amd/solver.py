@@ -161,6 +161,10 @@ class Solver:
             mask |= 1 << _lib.PH_NAMES.index(nm)
         _lib.check(self.L.sphhip_set_profiling_mask(self.h, mask))
 
+    def set_profiling_period(self, period):
+        """Bracket the selected phases in every `period`-th step only (an event pair costs the stream ~11 us)."""
+        _lib.check(self.L.sphhip_set_profiling_period(self.h, int(period)))
+
     def reset_phase_times(self):
         _lib.check(self.L.sphhip_reset_phase_times(self.h))
 
