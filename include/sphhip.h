@@ -152,7 +152,9 @@ int sphhip_forces(SphCtx* ctx, float mouse_x, float mouse_y, float strength);
 int sphhip_integrate(SphCtx* ctx);
 /* serial_stepSimulation (SPH/sph.cpp:166-171) x nsteps with the state resident on the device:
  * grid, density, then forces + velocity update + integrate + wall clamp fused in one kernel.
- * Replaces the 3-kernel loop of CUDA_performance_test (SPH/sph.cu:254-258). */
+ * Replaces the 3-kernel loop of CUDA_performance_test (SPH/sph.cu:254-258).  Asynchronous, but the host is kept
+ * less than 64 steps ahead of the GPU (it waits on an event every 32 steps): what the library decides from its
+ * kernels' reports through mapped memory must not be hundreds of steps old. */
 int sphhip_step(SphCtx* ctx, float mouse_x, float mouse_y, float strength, int nsteps);
 /* NO COUNTERPART IN THE REFERENCE.  The same steps as sphhip_step for callers that cannot allocate device memory
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): no context, no hipMalloc /
