@@ -1002,7 +1002,7 @@ static int split_enqueue(SphCtx* c, int send_hi_left, int send_lo_right, int kee
 // [nb, 2 nb) the right one; record slots are claimed with one atomic per workgroup pass on a counter in
 // the context, and the last workgroup to finish (ticket) writes both counts into the message headers and
 // re-arms the counters: no memset, no host round trip.
-constexpr int PACK_BLOCKS = 16;
+constexpr int PACK_BLOCKS = 64;  // (3 boundary columns of a 1 M slab are 12 k particles: one pass of 64 workgroups; 16 took three passes, 9 us)
 
 __global__ __launch_bounds__(256) void k_pack_boundary(DevConsts c, const float2* __restrict__ pos,
                                                         const float2* __restrict__ vel,
