@@ -153,7 +153,7 @@ static hipError_t dmalloc(T** p, size_t count) {
 static void free_all(SphCtx* c) {
     void* ptrs[] = {c->pos, c->vel, c->pos2, c->vel2, c->rho, c->prs, c->rho2, c->prs2, c->idv, c->idv2,
                     c->ncount, c->nmask, c->keys, c->keys2, c->perm, c->perm2, c->ids_sorted, c->cell_buf[0], c->cell_buf[1], c->block_hist,
-                    c->digit_total, c->scan_tmp, c->counters, c->tile_list, c->staging, c->dense_list, c->big_list, c->nmask_hi};
+                    c->digit_total, c->scan_tmp, c->counters, c->tile_list, c->staging, c->dense_list, c->big_list, c->nmask_hi, c->d_sinks, c->d_consts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int ph = 0; ph < SPHHIP_PH_COUNT; ph++) {
@@ -248,11 +248,37 @@ static void ctx_buffers(SphCtx* c, bool with_staging, F&& f) {
     c->dense_cap = c->n_max / 4 + 64;
     if (const char* e = getenv("SPHHIP_DENSE_CAP")) c->dense_cap = std::max(1, atoi(e));  // (tests: force an overflow)
     f((void**)&c->dense_list, sizeof(int4) * (size_t)c->dense_cap, false);
+    f((void**)&c->d_sinks, sizeof(DenseSinkDev) * 2, true);
+    f((void**)&c->d_consts, sizeof(DevConsts), true);
     c->big_cap = c->n_max / RANK_BIG_MIN + 1;  // (no more cells than that can be above RANK_BIG_MIN)
     f((void**)&c->big_list, sizeof(int) * (size_t)c->big_cap, true);
     // mask words 8..13 of long stencil ranges (allocated last: the layout of everything above is as it was without them)
     f((void**)&c->nmask_hi, sizeof(uint32_t) * n * (PAIR_MASK_WORDS_MAX - 8), false);
     if (with_staging) f(&c->staging, std::max<size_t>(n * SPHHIP_PARTICLE_BYTES, 64), false);
+}
+
+// The constant halves of the two dense-sub-tile sinks (pairs.hip: DenseSink) go to device memory once per context;
+// by kernel, with the values as kernel arguments: no host buffer has to outlive an asynchronous copy, nothing allocates.
+__global__ void k_write_sinks(DenseSinkDev* out, DenseSinkDev density, DenseSinkDev force, DevConsts* consts_out, DevConsts consts) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = density;
+        out[1] = force;
+        *consts_out = consts;
+    }
+}
+
+static int ctx_write_sinks(SphCtx* c) {
+    DenseSinkDev s[2];
+    for (int which = 0; which < 2; which++) {
+        s[which].list = c->dense_list;
+        s[which].count = c->counters + SPH_DENSE_COUNT_SLOT;
+        s[which].capacity = c->dense_cap;
+        s[which].host_flag = c->d_dense + which;
+        s[which].err = c->d_err;
+    }
+    hipLaunchKernelGGL(k_write_sinks, dim3(1), dim3(64), 0, c->stream, c->d_sinks, s[0], s[1], c->d_consts, c->dc);
+    LAUNCH_CHECK();
+    return SPHHIP_OK;
 }
 
 // Pointers into those buffers, and the state of a context that holds no particles yet.
@@ -331,6 +357,16 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
         free_all(c);
         delete c;
         return sph_hip_fail(e, "sphhip_create allocation", __FILE__, __LINE__);
+    }
+    if (int rc = ctx_write_sinks(c)) {
+        free_all(c);
+        delete c;
+        return rc;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {
+        free_all(c);
+        delete c;
+        return fail(SPHHIP_EHIP, "sphhip_create: hipStreamSynchronize failed");
     }
     *out = c;
     return SPHHIP_OK;
@@ -1469,6 +1505,7 @@ extern "C" int sphhip_step_static(const SphParams* p, int device, const void* d_
     // The array keeps the last call's contents: everything that must start at zero (counters, cell tables, index
     // arrays, tile list) is cleared -- simply all of the part in use.
     HIP_TRY(hipMemsetAsync(sl.ptr, 0, off, c->stream));
+    if ((rc = ctx_write_sinks(c))) return rc;
     hipLaunchKernelGGL(k_unpack_aos, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)d_aos_in, n, 0u, c->pos,
                        c->vel, c->rho, c->prs, c->idv);
     LAUNCH_CHECK();

@@ -10,6 +10,15 @@
 // Constants handed to every kernel by value.  All folded on the host with the reference's
 // expression order (sphhip_derive); kernels never call powf.
 // ---------------------------------------------------------------------------------------------
+// The constant part of a pair kernel's dense-sub-tile sink (pairs.hip: DenseSink), one per pass, in device memory.
+struct DenseSinkDev {
+    int4* list;      // (col, first row, rows, part)
+    int* count;
+    int capacity;
+    int* host_flag;  // mapped host memory
+    int* err;
+};
+
 struct DevConsts {
     float h, h2, poly6, spiky, visc_lap, visc_mass, neg_mass, lj_cut, lj24, sigma, mass;
     float stiffness, rest_density, gravity, force_cap, mouse_radius, mouse_r2;
@@ -112,6 +121,8 @@ struct SphCtx {
     int num_cus = 256;
     int* h_host_tiles = nullptr;                 // mapped host ints: tile count of a recent launch (-1: none yet), its tile_cells, long entries (-1: unknown)
     int* d_host_tiles = nullptr;                 // its device address
+    DenseSinkDev* d_sinks = nullptr;             // [0] density pass, [1] force pass
+    DevConsts* d_consts = nullptr;               // device copy of dc: k_force reads its epilogue constants from here
     int4* dense_list = nullptr;                  // dense sub-tiles of the running pair kernel (pairs.hip: DenseSink)
     int dense_cap = 0;                           // its capacity in entries
     int* big_list = nullptr;                     // crowded cells of the current grid build (k_scan_apply -> k_rank_big)
