@@ -696,3 +696,29 @@ def test_tile_stats_and_long_tiles():
         st = s.tile_stats()
     assert st["long"] > 0 and st["dense_force"] == 0, st
     assert orc.same_bits(got, O.step_cells(P, a.copy(), 4))
+
+
+def test_profiling_period_samples_steps():
+    """sphhip_set_profiling_period: phases are bracketed in steps 1, 1 + period, ... only; results do not change."""
+    params, a = scenes.dam_break(64)
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.set_profiling_phases(["force"])
+        s.set_profiling_period(8)
+        s.reset_phase_times()
+        s.stepSimulation(nsteps=20)
+        s.synchronize()
+        ms, k = s.phase_times()["force"]
+        assert k == 3 and ms > 0.0  # steps 1, 9, 17
+        assert s.phase_times()["density"][1] == 0
+        s.set_profiling_period(1)
+        s.reset_phase_times()
+        s.stepSimulation(nsteps=4)
+        s.synchronize()
+        assert s.phase_times()["force"][1] == 4
+        s.set_profiling(False)
+        got = s.download()
+    assert orc.same_bits(got, O.step_cells(params, a.copy(), 24))
+    with pytest.raises(Exception):
+        with Solver(params, n_max=len(a)) as s:
+            s.set_profiling_period(0)
