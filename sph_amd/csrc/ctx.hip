@@ -249,7 +249,7 @@ static void ctx_buffers(SphCtx* c, bool with_staging, F&& f) {
     if (const char* e = getenv("SPHHIP_DENSE_CAP")) c->dense_cap = std::max(1, atoi(e));  // (tests: force an overflow)
     f((void**)&c->dense_list, sizeof(int4) * (size_t)c->dense_cap, false);
     f((void**)&c->d_sinks, sizeof(DenseSinkDev) * 2, true);
-    f((void**)&c->d_consts, sizeof(DevConsts), true);
+    f((void**)&c->d_consts, sizeof(ForceExtraDev), true);
     c->big_cap = c->n_max / RANK_BIG_MIN + 1;  // (no more cells than that can be above RANK_BIG_MIN)
     f((void**)&c->big_list, sizeof(int) * (size_t)c->big_cap, true);
     // mask words 8..13 of long stencil ranges (allocated last: the layout of everything above is as it was without them)
@@ -259,7 +259,7 @@ static void ctx_buffers(SphCtx* c, bool with_staging, F&& f) {
 
 // The constant halves of the two dense-sub-tile sinks (pairs.hip: DenseSink) go to device memory once per context;
 // by kernel, with the values as kernel arguments: no host buffer has to outlive an asynchronous copy, nothing allocates.
-__global__ void k_write_sinks(DenseSinkDev* out, DenseSinkDev density, DenseSinkDev force, DevConsts* consts_out, DevConsts consts) {
+__global__ void k_write_sinks(DenseSinkDev* out, DenseSinkDev density, DenseSinkDev force, ForceExtraDev* consts_out, ForceExtraDev consts) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         out[0] = density;
         out[1] = force;
@@ -276,7 +276,10 @@ static int ctx_write_sinks(SphCtx* c) {
         s[which].host_flag = c->d_dense + which;
         s[which].err = c->d_err;
     }
-    hipLaunchKernelGGL(k_write_sinks, dim3(1), dim3(64), 0, c->stream, c->d_sinks, s[0], s[1], c->d_consts, c->dc);
+    ForceExtraDev x;
+    x.c = c->dc;
+    x.nmask_hi = c->nmask_hi;
+    hipLaunchKernelGGL(k_write_sinks, dim3(1), dim3(64), 0, c->stream, c->d_sinks, s[0], s[1], c->d_consts, x);
     LAUNCH_CHECK();
     return SPHHIP_OK;
 }

@@ -909,8 +909,8 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
                                             const uint32_t* __restrict__ skeys, const int* __restrict__ cell_start,
                                             float2* __restrict__ pos_o, float2* __restrict__ vel_o, const TileDesc& d,
                                             int cap, int own_lo_col, int own_hi_col, float mx, float my, float strength,
-                                            int allow_fast, const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ nmask_hi, int n_max,
-                                            const DenseSink& sink, const DevConsts* cdev, PairRec* s_rec, int* s_off, int* s_gs, int* s_wave,
+                                            int allow_fast, const uint32_t* __restrict__ nmask, int n_max,
+                                            const DenseSink& sink, const ForceExtraDev* cdev, PairRec* s_rec, int* s_off, int* s_gs, int* s_wave,
                                             uint8_t* s_q, int tix STAMP_PARAM) {
     STAMP(0);  // entry start
     // ghost column of a slab: pass the particles through
@@ -1067,10 +1067,17 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
                 const int nw_i = (hi - j + 31) >> 5;
                 const int npass = long_here ? 2 : 1;
 #pragma nounroll
-                for (int pass = 0; pass < npass; pass++)
-                    force_by_mask<THREADS>(c, s_rec, s_mask, pass ? nmask_hi + s : (const uint32_t*)nullptr,
+                for (int pass = 0; pass < npass; pass++) {
+                    const uint32_t* hi_words = nullptr;
+                    if (pass) {  // (the array of words 8..13: its address from device memory, only when it is needed)
+                        const ForceExtraDev* xp = cdev;
+                        asm volatile("" : "+s"(xp) : : "memory");
+                        hi_words = xp->nmask_hi + s;
+                    }
+                    force_by_mask<THREADS>(c, s_rec, s_mask, hi_words,
                                            n_max, j + pass * FORCE_MAX_RANGE, min(max(nw_i - pass * PAIR_MASK_WORDS, 0), PAIR_MASK_WORDS),
                                            self, pi, vi, pres_i, fx, fy, tix);
+                }
             } else if (fast)
                 force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
             else
@@ -1099,9 +1106,9 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
                 // The epilogue's dozen constants (gravity, force cap, mouse, dt, velocity cap, damping, walls) are read
                 // from the context's device copy here, behind an opaque pointer, instead of sitting in scalar registers
                 // through the whole pair loop as kernel arguments do: k_force has no scalar register to spare.
-                const DevConsts* cp = cdev;
+                const ForceExtraDev* cp = cdev;
                 asm volatile("" : "+s"(cp) : : "memory");
-                const DevConsts ce = *cp;
+                const DevConsts ce = cp->c;
                 force_epilogue<FUSE>(ce, fx, fy, pi, vi, dens_i, mx, my, strength);
                 if (FUSE) integrate_one(ce, pi, vi);
             }
@@ -1119,8 +1126,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
     const float* __restrict__ prs, const uint32_t* __restrict__ idv, const uint32_t* __restrict__ skeys,
     const int* __restrict__ cell_start, float2* __restrict__ pos_o, float2* __restrict__ vel_o, TileQueue q, int col_lo,
     int col_hi, int skip_lo, int skip_hi, int cap, int own_lo_col, int own_hi_col, float mx, float my,
-    float strength, int allow_fast, const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ nmask_hi, int n_max,
-    DenseSink sink, const DevConsts* __restrict__ cdev) {
+    float strength, int allow_fast, const uint32_t* __restrict__ nmask, int n_max,
+    DenseSink sink, const ForceExtraDev* __restrict__ cdev) {
     extern __shared__ __align__(16) float4 s_dyn[];
     PairRec* s_rec = reinterpret_cast<PairRec*>(s_dyn);
     int* s_off = reinterpret_cast<int*>(s_rec + cap);
@@ -1140,7 +1147,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
         // boundaries first and the interior in a second launch (sph_force_launch)
         if (d.col < col_lo || d.col >= col_hi || (d.col >= skip_lo && d.col < skip_hi)) return;
         force_entry<FUSE, THREADS, LONG>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, d, cap, own_lo_col,
-                                   own_hi_col, mx, my, strength, allow_fast, nmask, nmask_hi, n_max, sink, cdev, s_rec, s_off, s_gs, s_wave,
+                                   own_hi_col, mx, my, strength, allow_fast, nmask, n_max, sink, cdev, s_rec, s_off, s_gs, s_wave,
                                    s_q, tix STAMP_ARG);
     });
 }
@@ -1889,14 +1896,14 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
         HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->side_stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
                            c->cell_start, pout, vout, q, il, ih, 0, 0, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength,
-                           c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->nmask_hi, c->n_max, sink, c->d_consts);
+                           c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink, c->d_consts);
         LAUNCH_CHECK();
         HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
         beside = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
                        c->cell_start, pout, vout, q, lo, hi, skip_lo, skip_hi, c->pair_cap, c->col_lo, c->col_hi,
-                       mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->nmask_hi, c->n_max, sink, c->d_consts);
+                       mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink, c->d_consts);
     LAUNCH_CHECK();
     if (sink.mode & 1) {
         auto dkern = tp ? (fuse_integrate ? k_force_dense_tp<true> : k_force_dense_tp<false>)

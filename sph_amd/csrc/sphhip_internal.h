@@ -28,6 +28,13 @@ struct DevConsts {
     int nx, ny;
 };
 
+// What k_force needs rarely, in device memory instead of kernel arguments (scalar registers): the constants again, for
+// the epilogue, and the array of mask words 8..13 (long tiles only).
+struct ForceExtraDev {
+    DevConsts c;
+    const uint32_t* nmask_hi;
+};
+
 // idv word: particle id in bits 0..30, bit 31 set when the reference's `valid` flag is false.
 #define SPH_INVALID_BIT 0x80000000u
 #define SPH_ID_MASK 0x7fffffffu
@@ -122,7 +129,7 @@ struct SphCtx {
     int* h_host_tiles = nullptr;                 // mapped host ints: tile count of a recent launch (-1: none yet), its tile_cells, long entries (-1: unknown)
     int* d_host_tiles = nullptr;                 // its device address
     DenseSinkDev* d_sinks = nullptr;             // [0] density pass, [1] force pass
-    DevConsts* d_consts = nullptr;               // device copy of dc: k_force reads its epilogue constants from here
+    ForceExtraDev* d_consts = nullptr;           // device copy of dc (+ rarely used pointers): k_force reads its epilogue constants from here
     int4* dense_list = nullptr;                  // dense sub-tiles of the running pair kernel (pairs.hip: DenseSink)
     int dense_cap = 0;                           // its capacity in entries
     int* big_list = nullptr;                     // crowded cells of the current grid build (k_scan_apply -> k_rank_big)
