@@ -203,7 +203,6 @@ static void ctx_configure(SphCtx* c, const SphParams& p, const SphDerived& d, in
     if (const char* e = getenv("SPHHIP_RANK_BIG")) c->rank_big = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_TILE_LIST_FUSED")) c->tile_list_fused = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_SPLIT_CONCURRENT")) c->split_concurrent = atoi(e) != 0;
-    if (const char* e = getenv("SPHHIP_LONG_TILES")) c->long_mode = atoi(e) != 0 ? 1 : 0;
     if (c->rank_big && sph_rank_big_setup() != SPHHIP_OK) c->rank_big = false;  // (no 128 KB LDS opt-in: the loop ranks everything)
     if (const char* e = getenv("SPHHIP_DENSE_TP")) c->dense_tp = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_LAZY_PACK")) c->lazy_pack = atoi(e) != 0;
@@ -646,7 +645,7 @@ static std::vector<uint64_t> step_sig(const SphCtx* c, float mx, float my, float
             (uint64_t)c->pair_threads, (uint64_t)c->grid_valid, (uint64_t)c->counts_valid, (uint64_t)c->slice_valid,
             (uint64_t)c->tiles_valid, (uint64_t)c->cell_next_zeroed, (uint64_t)c->mask_tile_cells, (uint64_t)c->mask_cap,
             (uint64_t)c->tab_clo, (uint64_t)c->tab_chi, (uint64_t)c->use_masks, (uint64_t)c->fast_div,
-            (uint64_t)(dd != 0), (uint64_t)(df != 0), (uint64_t)(c->long_hold > 0 || ((volatile int*)c->h_host_tiles)[2] < 0), f(mx), f(my), f(strength)};
+            (uint64_t)(dd != 0), (uint64_t)(df != 0), f(mx), f(my), f(strength)};
 }
 
 static bool graph_possible(const SphCtx* c) {

@@ -902,7 +902,7 @@ struct OwnParticle {
 // One list entry of the force pass.  Prologue as in density_entry: the candidate-cell table, the own particles, their
 // mask words (only as many as the entry's longest stencil range needs) and the candidates' records (contiguous
 // slot ranges straight from the entry) are all requested before the first wait; three barriers in all.
-template <bool FUSE, int THREADS, bool LONG>
+template <bool FUSE, int THREADS>
 __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __restrict__ pos,
                                             const float2* __restrict__ vel, const float* __restrict__ rho,
                                             const float* __restrict__ prs, const uint32_t* __restrict__ idv,
@@ -922,13 +922,11 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
         return;
     }
     TileGeom g = entry_geom(c, d);
-    // a "long" tile (some stencil range above FORCE_MAX_RANGE records) needs the masks: two passes over their words
-    // (LONG = false: the kernel the host launches while the list holds no long tile; one that turns up takes the way of the
-    // dense sub-tiles.  Handling them costs this kernel a few scalar registers too many: 3-5 % at 16 M particles.)
+    // a "long" tile (some stencil range above FORCE_MAX_RANGE records) needs the masks: two passes over their words;
+    // without masks it goes the way of the dense sub-tiles
     const int nw_all = d.info & 0xff;
     const bool long_tile = nw_all > PAIR_MASK_WORDS;
-    const bool long_here = LONG && long_tile;
-    bool use_lds = (d.info & TILE_DENSE) == 0 && !(long_tile && (!LONG || !nmask));
+    bool use_lds = (d.info & TILE_DENSE) == 0 && !(long_tile && !nmask);
     if (!use_lds && dense_defer(sink, g, tix, c.nx, c.ny)) return;
     const float inf = __builtin_inff();
     int* s_flags = s_wave + 7;
@@ -1023,7 +1021,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
         const int all = *s_flags;
         fast = (all & 1) == 0;
         by_mask = fast && (all & 2) == 0;
-        if (long_here && !by_mask) {
+        if (long_tile && !by_mask) {
             // the masks cannot be used after all (an operand outside the safe range, an invalid or non-finite candidate)
             // and the scan path's byte queue does not reach beyond FORCE_MAX_RANGE: the way of the dense sub-tiles
             if (dense_defer(sink, g, tix, c.nx, c.ny)) return;
@@ -1061,22 +1059,20 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
                 self = s_off[self_cell] + (s - s_gs[self_cell]);
             }
             if (by_mask) {
-                // A long tile takes two passes: the candidates beyond the first 8 mask words follow with their words
+                // A long tile takes a second pass: the candidates beyond the first 8 mask words follow with their words
                 // fetched from global memory (ascending candidates, the same order; lanes whose range is shorter
-                // evaluate themselves meanwhile: terms of +0).  One loop, so that the pop loop exists once in the code.
+                // evaluate themselves meanwhile: terms of +0).  Two call sites, not one loop over the passes: with
+                // the loop every tile paid for the second pass (k_force 6 % slower at 16M particles, long tiles or
+                // not -- which is why the kernel once had an instantiation without it, picked by the host); with the
+                // first pass's word pointer a compile-time null it costs nothing (1.78 -> 1.77 ms there, the evolved
+                // 1M dam break with its 8 long tiles 0.274 -> 0.258 ms per step).
                 const int nw_i = (hi - j + 31) >> 5;
-                const int npass = long_here ? 2 : 1;
-#pragma nounroll
-                for (int pass = 0; pass < npass; pass++) {
-                    const uint32_t* hi_words = nullptr;
-                    if (pass) {  // (the array of words 8..13: its address from device memory, only when it is needed)
-                        const ForceExtraDev* xp = cdev;
-                        asm volatile("" : "+s"(xp) : : "memory");
-                        hi_words = xp->nmask_hi + s;
-                    }
-                    force_by_mask<THREADS>(c, s_rec, s_mask, hi_words,
-                                           n_max, j + pass * FORCE_MAX_RANGE, min(max(nw_i - pass * PAIR_MASK_WORDS, 0), PAIR_MASK_WORDS),
-                                           self, pi, vi, pres_i, fx, fy, tix);
+                force_by_mask<THREADS>(c, s_rec, s_mask, nullptr, n_max, j, min(nw_i, PAIR_MASK_WORDS), self, pi, vi, pres_i, fx, fy, tix);
+                if (long_tile) {  // (the array of words 8..13: its address from device memory, only when it is needed)
+                    const ForceExtraDev* xp = cdev;
+                    asm volatile("" : "+s"(xp) : : "memory");
+                    force_by_mask<THREADS>(c, s_rec, s_mask, xp->nmask_hi + s, n_max, j + FORCE_MAX_RANGE,
+                                           min(max(nw_i - PAIR_MASK_WORDS, 0), PAIR_MASK_WORDS), self, pi, vi, pres_i, fx, fy, tix);
                 }
             } else if (fast)
                 force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
@@ -1120,7 +1116,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
     STAMP_VAL(6, __builtin_amdgcn_s_memrealtime());
 }
 
-template <bool FUSE, int THREADS, bool LONG>
+template <bool FUSE, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_WAVES_MAX, FORCE_WAVES_MAX))) void k_force(
     DevConsts c, const float2* __restrict__ pos, const float2* __restrict__ vel, const float* __restrict__ rho,
     const float* __restrict__ prs, const uint32_t* __restrict__ idv, const uint32_t* __restrict__ skeys,
@@ -1146,7 +1142,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FORCE_W
         // columns [col_lo, col_hi) without [skip_lo, skip_hi): a slab step runs the columns next to the slab
         // boundaries first and the interior in a second launch (sph_force_launch)
         if (d.col < col_lo || d.col >= col_hi || (d.col >= skip_lo && d.col < skip_hi)) return;
-        force_entry<FUSE, THREADS, LONG>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, d, cap, own_lo_col,
+        force_entry<FUSE, THREADS>(c, pos, vel, rho, prs, idv, skeys, cell_start, pos_o, vel_o, d, cap, own_lo_col,
                                    own_hi_col, mx, my, strength, allow_fast, nmask, n_max, sink, cdev, s_rec, s_off, s_gs, s_wave,
                                    s_q, tix STAMP_ARG);
     });
@@ -1858,22 +1854,8 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     const bool masks_ok = second ? c->split.masks_ok
                                  : c->use_masks && c->counts_valid && c->grid_valid && c->mask_tile_cells == c->tile_cells &&
                                        c->mask_cap == c->pair_cap;
-    // long tiles (stencil ranges of 257..448 records) are handled in place only by the LONG instantiation, launched while
-    // the list holds any (going by what the last launch reported; -1 = not known yet)
-    // (with hysteresis: the count flickers between 0 and 1 in a scene that has just reached that density, and a long tile
-    // met by the other instantiation costs a dense follow-up launch)
-    const int long_seen = ((volatile int*)c->h_host_tiles)[2];  // (-1: no launch has reported yet)
-    if (!second) {
-        if (long_seen > 0)
-            c->long_hold = 64;
-        else if (c->long_hold > 0)
-            c->long_hold--;
-    }
-    const bool lng = second ? c->split.long_kernel : (c->long_mode < 0 ? (long_seen < 0 || c->long_hold > 0) : c->long_mode != 0);
-    auto kern = lng ? (fuse_integrate ? (th == 128 ? k_force<true, 128, true> : k_force<true, 256, true>)
-                                      : (th == 128 ? k_force<false, 128, true> : k_force<false, 256, true>))
-                    : (fuse_integrate ? (th == 128 ? k_force<true, 128, false> : k_force<true, 256, false>)
-                                      : (th == 128 ? k_force<false, 128, false> : k_force<false, 256, false>));
+    auto kern = fuse_integrate ? (th == 128 ? k_force<true, 128> : k_force<true, 256>)
+                               : (th == 128 ? k_force<false, 128> : k_force<false, 256>);
     int grid = 0;
     if ((rc = pair_grid(c, reinterpret_cast<const void*>(kern), th, lds, grid))) return rc;
     DenseSink sink;
@@ -1925,7 +1907,6 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     if (part == 1) {
         c->split.pending = true;
         c->split.interior_enqueued = beside;
-        c->split.long_kernel = lng;
         c->split.masks_ok = masks_ok;
         c->split.il = il;
         c->split.ih = ih;

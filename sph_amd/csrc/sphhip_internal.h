@@ -134,8 +134,6 @@ struct SphCtx {
     int dense_cap = 0;                           // its capacity in entries
     int* big_list = nullptr;                     // crowded cells of the current grid build (k_scan_apply -> k_rank_big)
     int big_cap = 0;
-    int long_hold = 0;                           // force launches left with the LONG instantiation after the last report of long tiles
-    int long_mode = -1;                          // SPHHIP_LONG_TILES=0 / 1: never / always the LONG instantiation (-1: by the reports)
     bool tile_list_fused = true;                 // the work list is built by head workgroups of k_cell_scatter (SPHHIP_TILE_LIST_FUSED=0: own launch)
     bool rank_big = true;                        // SPHHIP_RANK_BIG=0: in-cell ranking always by k_rank_reorder's loop
     int* h_dense = nullptr;                      // mapped host ints: entries of the last dense density / force kernel (-1: unknown)
@@ -155,7 +153,6 @@ struct SphCtx {
         bool pending = false, masks_ok = false;
         int il = 0, ih = 0;  // interior columns
         int edge_l = 0, edge_r = 0;  // owned columns sphhip_step_begin finished on each side
-        bool long_kernel = false;        // the force kernel instantiation of the first half (the second uses the same)
         bool interior_enqueued = false;  // sphhip_step_begin already started the interior pass on the side stream
         float mx = 0, my = 0, strength = 0;
     } split;

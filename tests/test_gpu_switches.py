@@ -26,7 +26,7 @@ O = orc.Oracle()
 P = O.default_params()
 
 SWITCHES = [("SPHHIP_GRID", "radix"), ("SPHHIP_USE_MASKS", "0"), ("SPHHIP_FAST_DIV", "0"), ("SPHHIP_SMALL_GRID", "0"),
-            ("SPHHIP_LAZY_PACK", "0"), ("SPHHIP_TILE_LIST_FUSED", "0"), ("SPHHIP_LONG_TILES", "0"), ("SPHHIP_LONG_TILES", "1")]
+            ("SPHHIP_LAZY_PACK", "0"), ("SPHHIP_TILE_LIST_FUSED", "0")]
 
 
 def _scenes():
