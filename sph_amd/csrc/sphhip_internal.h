@@ -394,7 +394,11 @@ __device__ __forceinline__ void sph_tile_list_thread(int i, const int* __restric
         cy0 = trow * tl.tile_cells;
         cy1 = min(cy0 + tl.tile_cells, ny);
         bool walk = true;
-        if (tl.tile_cells <= TILE_FAST_ROWS) {
+        // (an empty base tile -- three quarters of a dam break's grid, nearly all of the last slab's in a wide domain --
+        // is recognised from the two ends of its slot range before anything else is loaded)
+        if (cell_start[col * ny + cy1] == cell_start[col * ny + cy0]) {
+            walk = false;
+        } else if (tl.tile_cells <= TILE_FAST_ROWS) {
             // Fast path (the normal case: the base tile fits as a whole).  All boundaries of the tile's neighbourhood
             // are fetched with independent loads -- one memory round trip -- and the three limits are checked in
             // registers; only a base tile that has to be cut takes the row-by-row walk below.
