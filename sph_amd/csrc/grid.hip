@@ -331,6 +331,15 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
     int s = ((int)blockIdx.x - head_blocks) * blockDim.x + threadIdx.x;
     if (s >= n) return;
     uint32_t k = skeys[s];
+    // (the state is gathered first: its loads depend on perm only and travel while the chain key -> cell table -> ids runs)
+    const uint32_t src = perm[s];
+    const float2 p_in = pos[src], v_in = vel[src];
+    const uint32_t id_in = idv[src];
+    float d_in = 0.0f, pr_in = 0.0f;
+    if (CARRY_DENSITY) {
+        d_in = rho[src];
+        pr_in = prs[src];
+    }
     if (k >= (uint32_t)ncell) return;  // (never for a slot below the count; a stale key must not become an address)
     int a = cell_start[k], b = cell_start[k + 1];
     // a crowded cell is ranked by k_rank_big (sorted ids instead of this loop over all cell-mates)
@@ -339,14 +348,13 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
     int rank = 0;
     for (int t = a; t < b; t++) rank += (ids_sorted[t] < my) ? 1 : 0;
     int dst = a + rank;
-    uint32_t src = perm[s];
-    pos_o[dst] = pos[src];
-    vel_o[dst] = vel[src];
+    pos_o[dst] = p_in;
+    vel_o[dst] = v_in;
     if (CARRY_DENSITY) {
-        rho_o[dst] = rho[src];
-        prs_o[dst] = prs[src];
+        rho_o[dst] = d_in;
+        prs_o[dst] = pr_in;
     }
-    idv_o[dst] = idv[src];
+    idv_o[dst] = id_in;
 }
 
 // The same ranking for crowded cells.  The loop above reads every cell-mate's id per particle: quadratic in the cell
