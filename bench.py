@@ -2,35 +2,42 @@
 """Headline benchmark: particle-updates/s of the full SPH step (cell list + density/pressure +
 force + integrate/boundary) with the state resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dam1m|box4m|dam16m|...]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dam1m|box4m|dam16m|dam8m|...]
+                  [--scaling weak|strong] [--driver c10d|mg] [--repeats R]
 
 N = 1: BASELINE.json configs[1], the 2-D dam break with 1M particles (1024 x 1024 lattice at
-spacing H/4 against the left wall of a 4W x 2W box, all sph.h constants).  N > 1 (launched by
-torch.distributed.run, one rank per GPU): x-slab decomposition with ghost-column halo exchange and
-migration over RCCL (sph_amd/slab.py); per-GPU work is fixed (weak scaling): the column gets N
-times wider.
+spacing H/4 against the left wall of a 4W x 2W box, all sph.h constants).
+
+N > 1: BASELINE.json configs[3], the 16M-particle dam break split into N x-slabs (strong scaling;
+ghost-column halo exchange and particle migration between x-neighbours over RCCL), and in the same
+JSON line configs[4] (8M particles per GPU, weak scaling) and the 16M scene on one GPU.  One rank
+per GPU over torch.distributed (sph_amd/slab.py): launched by `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`, or by this script itself when it is started plainly
+(`python bench.py --gpus N`): the ranks are then spawned as fresh child processes before this
+process has touched the GPU.  `--driver mg` runs the same decomposition through the C++ driver
+libsph_mg.so instead: ONE process, ncclCommInitAll, one enqueue thread per slab
+(include/sph_mg.h).  On a box with fewer GPUs than N the run is refused unless
+SPH_BENCH_SHARE_GPU=1 puts all slabs on device 0 (a protocol rehearsal, not a measurement:
+messages then travel through host memory / device copies).
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (fused force + integrate)
 by its ALGORITHMIC bytes (40 B/particle: R pos 8, vel 8, rho 4, P 4; W pos 8, vel 8; neighbour
 gathers are served by LDS/L2 and not counted) over its average launch time,
-measured with HIP events on the library's stream inside the timed region.  `cpu_baseline` is the
-oracle's portable restatement of the reference's OpenMP path (SPH/openMP_sph.cpp:80-205,
-all-pairs) timed on this host's cores on a bounded miniature of the same scene.
+measured with HIP events on the stream the kernel runs on, inside the timed region.
+`cpu_baseline` is the oracle's portable restatement of the reference's OpenMP path
+(SPH/openMP_sph.cpp:80-205, all-pairs) timed on this host's cores on a bounded miniature of the
+same scene.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-from sph_amd import scenes  # noqa: E402
-from sph_amd.solver import Solver  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X peak FP32 vector (MI355X_MICROARCH.md)
@@ -41,20 +48,26 @@ FORCE_BYTES_PER_PARTICLE = 40  # fused force + integrate, SURVEY.md 8(d)
 # algorithmic flops, SURVEY.md 8(d): per stencil candidate 7 (2 sub, 2 mul, add, cmp, select), per in-range density
 # pair +6, per in-range force pair +45 (div and sqrt counted as 1 each), per particle epilogue ~25
 FLOP_CANDIDATE, FLOP_DENSITY_PAIR, FLOP_FORCE_PAIR, FLOP_EPILOGUE = 7, 6, 45, 25
+PAIR_SLOTS_PER_CU = 4  # workgroups of k_force resident per CU (LDS budget of 960 records, pairs.hip)
 
 WORKLOADS = {
-    # name: (kind, lattice columns per GPU, rows)
+    # name: (kind, lattice columns (per GPU when weak scaling), rows)
     "dam1m": ("dam", 1024, 1024),
     "dam4m": ("dam", 2048, 2048),
     "dam16m": ("dam", 4096, 4096),
     "dam8m": ("dam", 2896, 2896),
     "box4m": ("box", 2048, 2048),
     "dam64k": ("dam", 256, 256),
+    "dam256k": ("dam", 512, 512),
 }
 
 
-def cpu_baseline(n_gpus):
+def cpu_baseline():
     """Times the oracle's OpenMP all-pairs port (and the cell-list oracle) on this host."""
+    import numpy as np  # noqa: F401
+
+    from sph_amd import scenes
+
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     try:
         import orc
@@ -104,6 +117,8 @@ def cpu_baseline(n_gpus):
 def stencil_candidates(solver, drv):
     """Sum over particles of the population of their 3x3 cell stencil (the candidates a cell-list pass tests), from
     the cell table of the current grid.  Host numpy, off the timed path."""
+    import numpy as np
+
     solver.buildNeighbors()
     _, _, cs, ce = solver.cells()
     cnt = (ce - cs).astype(np.int64).reshape(drv.nx, drv.ny)
@@ -116,30 +131,77 @@ def stencil_candidates(solver, drv):
     return int((cnt * acc).sum())
 
 
-def force_rooflines(n_local, force_avg_s, pairs_local, cand_local, traffic=None, valu=None):
+def force_rooflines(n_launch, force_avg_s, pairs_local, cand_local, traffic=None, valu=None, kernel="k_force<fused integrate>"):
     """The two roofline blocks of the dominant kernel (fused force + integrate): HBM by algorithmic bytes, and FP32
-    vector by SURVEY.md 8(d)'s algorithmic flop counts (the bound that actually applies at ~50 neighbours)."""
-    achieved = FORCE_BYTES_PER_PARTICLE * n_local / force_avg_s / 1e9 if force_avg_s > 0 else 0.0
+    vector by SURVEY.md 8(d)'s algorithmic flop counts (the bound that actually applies at ~50 neighbours).
+    n_launch: particles the timed launch updates."""
+    achieved = FORCE_BYTES_PER_PARTICLE * n_launch / force_avg_s / 1e9 if force_avg_s > 0 else 0.0
     hbm = {
-        "kernel": "k_force<fused integrate>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": force_avg_s * 1e3,
-        "algorithmic_bytes_per_launch": FORCE_BYTES_PER_PARTICLE * n_local, "valu": valu,
+        "algorithmic_bytes_per_launch": FORCE_BYTES_PER_PARTICLE * n_launch, "valu": valu,
         "note": "pair kernels are VALU-bound at ~50 neighbours (no MFMA: irregular gathers); see roofline_valu and DESIGN.md",
     }
-    flops = FLOP_CANDIDATE * cand_local + FLOP_FORCE_PAIR * pairs_local + FLOP_EPILOGUE * n_local
-    tf = flops / force_avg_s / 1e12 if force_avg_s > 0 else 0.0
-    fp32 = {
-        "kernel": "k_force<fused integrate>", "bound": "valu_fp32", "achieved": tf, "peak": FP32_VALU_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TFLOPS, "flops_per_launch": flops,
-        "model": "SURVEY.md 8(d): 7 per stencil candidate + 45 per in-range pair + 25 per particle; candidates %d, in-range "
-                 "pairs %d" % (cand_local, pairs_local),
-    }
+    fp32 = None
+    if cand_local:
+        flops = FLOP_CANDIDATE * cand_local + FLOP_FORCE_PAIR * pairs_local + FLOP_EPILOGUE * n_launch
+        tf = flops / force_avg_s / 1e12 if force_avg_s > 0 else 0.0
+        fp32 = {
+            "kernel": kernel, "bound": "valu_fp32", "achieved": tf, "peak": FP32_VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TFLOPS, "flops_per_launch": flops,
+            "model": "SURVEY.md 8(d): 7 per stencil candidate + 45 per in-range pair + 25 per particle; candidates %d, in-range "
+                     "pairs %d" % (cand_local, pairs_local),
+        }
     return hbm, fp32
 
 
-def run_single(name, steps, warmup, device, evolve=0):
-    """One single-GPU scene: `evolve` untimed steps, `warmup` untimed steps, `steps` timed steps with HIP events around
-    the force kernel, then neighbour statistics.  Returns a dict (and the solver's scene description)."""
+def committed_pmc(name):
+    """HBM bytes per k_force launch and the VALU issue figures of the committed PMC profile of this workload
+    (profiles/traffic.json names it); None where there is none."""
+    traffic, valu = None, None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        ent = json.load(open(tf)).get(name, {})
+        traffic = ent.get("k_force_bytes_per_launch")
+        pm = json.load(open(os.path.join(ROOT, ent["source"])))
+        kf = [v for k, v in pm.items() if k.startswith("k_force<true")][0]
+        valu = {"cycles_per_wave_instruction": kf.get("valu_cycles_per_wave_instr"), "lane_utilisation": kf.get("valu_lane_utilisation"),
+                "wave_instructions_per_launch": kf.get("SQ_INSTS_VALU"), "source": ent["source"]}
+    except Exception:
+        pass
+    return traffic, valu
+
+
+def stats(values):
+    import numpy as np
+
+    v = np.asarray(values, float)
+    return {"repeats": len(v), "value_median": float(np.median(v)), "value_min": float(v.min()), "value_max": float(v.max()),
+            "spread": float((v.max() - v.min()) / np.median(v)) if len(v) else 0.0}
+
+
+def tile_rounds(solver):
+    """How the pair kernels' work list fills the GPU: entries, resident workgroup slots, rounds, and the share of the
+    last round's slots that stay idle (the launch tail)."""
+    st = solver.tile_stats()
+    slots = PAIR_SLOTS_PER_CU * 256
+    tiles = st["tiles"]
+    if tiles <= 0:
+        return None
+    rounds = tiles / slots
+    full = -(-tiles // slots)
+    return {"tiles": tiles, "slots": slots, "rounds": rounds, "tail_frac": (full * slots - tiles) / float(full * slots),
+            "long": st["long"], "dense_force": st["dense_force"]}
+
+
+def run_single(name, steps, warmup, device, evolve=0, repeats=1):
+    """One single-GPU scene: `evolve` untimed steps, `warmup` untimed steps, `repeats` timed intervals of `steps` steps
+    with HIP events around the force kernel, then neighbour statistics.  `value` is the FIRST interval."""
+    import torch
+
+    from sph_amd import scenes
+    from sph_amd.solver import Solver
+
     kind, cols, rows = WORKLOADS[name]
     params, a = scenes.dam_break(cols, rows) if kind == "dam" else scenes.uniform_box(cols)
     n = len(a)
@@ -153,28 +215,406 @@ def run_single(name, steps, warmup, device, evolve=0):
         solver.set_profiling_phases(["force"])
         solver.set_profiling_period(FORCE_SAMPLE_PERIOD)
         solver.reset_phase_times()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        solver.stepSimulation(nsteps=steps)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        times = []
+        for _ in range(max(repeats, 1)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            solver.stepSimulation(nsteps=steps)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        elapsed = times[0]
         f_ms, f_k = solver.phase_times()["force"]
+        solver.set_profiling(False)
+        rounds = tile_rounds(solver)
+        # per-phase breakdown: a few extra steps with every phase bracketed (not part of `value`)
+        solver.set_profiling_period(1)
+        solver.set_profiling(True)
+        solver.reset_phase_times()
+        solver.stepSimulation(nsteps=5)
+        torch.cuda.synchronize()
+        breakdown = {k: v[0] / 5 for k, v in solver.phase_times().items() if v[1]}
         solver.set_profiling(False)
         solver.computeDensityPressure()
         pairs = solver.pair_count()
         counts = solver.neighbor_counts()
         cand = stencil_candidates(solver, solver.drv)
         force_avg_s = (f_ms / max(f_k, 1)) * 1e-3  # (f_k: the sampled launches)
-        hbm, fp32 = force_rooflines(n, force_avg_s, pairs, cand)
-        return {
+        traffic, valu = committed_pmc(name if not evolve else "-")
+        hbm, fp32 = force_rooflines(n, force_avg_s, pairs, cand, traffic, valu)
+        out = {
             "workload": name, "particles": n, "grid": [solver.drv.nx, solver.drv.ny], "steps": steps, "warmup": warmup,
             "evolved_steps": evolve, "value": n * steps / elapsed, "unit": "particle-updates/s",
             "ms_per_step": elapsed / steps * 1e3, "mean_neighbors": pairs / max(n, 1),
             "max_neighbors": int(counts.max()) - 1 if n else 0,
             "pair_interactions_per_s": 2.0 * pairs * steps / elapsed,
-            "roofline": {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms")},
-            "roofline_valu": {k: fp32[k] for k in ("achieved", "peak", "unit", "frac")},
+            "roofline": hbm, "roofline_valu": fp32, "phases_ms_per_step": breakdown, "tile_rounds": rounds,
+            "box": [float(params.xmax - params.xmin), float(params.ymax - params.ymin)],
         }
+        if repeats > 1:
+            out.update(stats([n * steps / t for t in times]))
+        return out
+
+
+def brief(d):
+    """An extra scene's entry: the headline numbers without the long roofline notes."""
+    o = {k: d[k] for k in ("workload", "particles", "grid", "steps", "warmup", "evolved_steps", "value", "unit", "ms_per_step",
+                           "mean_neighbors", "max_neighbors", "pair_interactions_per_s", "tile_rounds") if k in d}
+    o["roofline"] = {k: d["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms")}
+    if d.get("roofline_valu"):
+        o["roofline_valu"] = {k: d["roofline_valu"][k] for k in ("achieved", "peak", "unit", "frac")}
+    return o
+
+
+def workload_text(kind, n_total, rows, params):
+    return "2D %s, %d particles (%d x %d lattice at spacing H/4, box %.1f x %.1f, sph.h constants), fp32" % (
+        "dam-break" if kind == "dam" else "uniform box filled wall to wall", n_total, n_total // rows, rows,
+        params.xmax - params.xmin, params.ymax - params.ymin)
+
+
+# ---- N > 1, one rank per GPU over torch.distributed (sph_amd/slab.py) -------------------------------------------------
+def run_slabs(name, scaling, steps, warmup, rebalance_every, local_rank, rank, world):
+    """One slab-decomposed scene on the ranks of the default process group; returns the result dict on rank 0 (None
+    elsewhere).  Timed region: barrier + device sync on both sides, MAX over ranks."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from sph_amd import lib as _lib
+    from sph_amd import scenes
+    from sph_amd.slab import HALO_COLS, PACK_REACH, make_hip_slab
+
+    kind, cols, rows = WORKLOADS[name]
+    # weak scaling: the fluid column gets `world` times wider, per-GPU particle count fixed;
+    # strong scaling: the named scene as it is, split into `world` slabs
+    total_cols = cols * world if scaling == "weak" else cols
+    sharded = scenes.dam_break_sharded if kind == "dam" else scenes.uniform_box_sharded
+    params, n_total, hist_fn, make_local = sharded(total_cols, rows)
+    drv = _lib.derive(params)
+    slab = make_hip_slab(params, make_local, local_rank, hist=hist_fn(drv))
+    inner = slab.solver
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+    def allmax(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_ints(x):
+        t = torch.zeros(world, dtype=torch.int64, device=dev)
+        t[rank] = int(x)
+        dist.all_reduce(t)
+        return [int(v) for v in t.cpu()]
+
+    def owned_now():
+        # particles in this rank's own columns (ghost copies lie outside them); synchronises, and raises if a halo
+        # message or the particle capacity overflowed during the asynchronous steps; leaves the state as it is
+        return int(slab.backend.column_histogram()[slab.c0:slab.c1].sum())
+
+    slab.run(warmup, rebalance_every)
+    torch.cuda.synchronize()
+    counts_start = gather_ints(owned_now())
+    # HIP events around the two force launches of a split step (boundary columns on the library's stream, interior
+    # columns on its side stream), one step in eight
+    inner.set_profiling_phases(["force", "force_interior"])
+    inner.set_profiling_period(FORCE_SAMPLE_PERIOD)
+    inner.reset_phase_times()
+    reb0 = slab.rebalances
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    slab.run(steps, rebalance_every)
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = allmax(time.perf_counter() - t0)
+    ph = inner.phase_times()
+    inner.set_profiling(False)
+    n_owned = owned_now()
+    counts_end = gather_ints(n_owned)
+    bytes_per_exchange = slab.bytes_per_exchange()
+    # breakdown of 5 more steps with every phase bracketed (not part of `value`)
+    inner.set_profiling_period(1)
+    inner.set_profiling(True)
+    inner.reset_phase_times()
+    slab.step(5)
+    torch.cuda.synchronize()
+    breakdown = {k: v[0] / 5 for k, v in inner.phase_times().items() if v[1]}
+    inner.set_profiling(False)
+    # the interior launch is the dominant kernel: particles it updates = owned minus the PACK_REACH columns per neighbour
+    slab.backend.drop_ghosts()
+    h = slab.backend.column_histogram()
+    il = slab.c0 + (PACK_REACH if rank > 0 else 0)
+    ih = slab.c1 - (PACK_REACH if rank < world - 1 else 0)
+    n_interior = int(h[il:ih].sum())
+    inner.set_owned_columns(0, drv.nx)  # count pairs over this rank's own particles only (edge pairs are missed)
+    inner.computeDensityPressure()
+    pairs = float(inner.pair_count())
+    t = torch.tensor([pairs], dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    pairs = float(t.item())
+    fi_ms, fi_k = ph["force_interior"]
+    fe_ms, fe_k = ph["force"]
+    interior_s = fi_ms / max(fi_k, 1) * 1e-3
+    if rank != 0:
+        del slab
+        return None
+    if fi_k:
+        hbm, _ = force_rooflines(n_interior, interior_s, 0, 0, kernel="k_force<fused integrate>, interior columns of rank 0's slab")
+        hbm["boundary_launch_ms"] = fe_ms / max(fe_k, 1)
+        hbm["note"] = ("split slab step: this launch runs on the side stream beside the boundary columns' launch (boundary_launch_ms); "
+                       "sampled one step in %d inside the timed region. " % FORCE_SAMPLE_PERIOD) + hbm["note"]
+    else:  # (one rank, or steps too few to sample a split step: the whole pass of the un-split steps)
+        hbm, _ = force_rooflines(n_owned, fe_ms / max(fe_k, 1) * 1e-3, 0, 0)
+    out = {
+        "workload": name, "scaling": scaling, "particles": n_total, "grid": [drv.nx, drv.ny], "steps": steps, "warmup": warmup,
+        "value": n_total * steps / elapsed, "unit": "particle-updates/s", "ms_per_step": elapsed / steps * 1e3,
+        "pair_interactions_per_s": 2.0 * pairs * steps / elapsed, "mean_neighbors": pairs / max(n_total, 1),
+        "roofline": hbm, "phases_ms_per_step_rank0": breakdown,
+        "slabs": {
+            "bounds": list(slab.bounds), "particles_per_rank_start": counts_start, "particles_per_rank_end": counts_end,
+            "rebalance_every": rebalance_every, "rebalances": slab.rebalances - reb0,
+            "transport": "c10d-" + dist.get_backend() + (" (messages staged through host memory)" if dist.get_backend() != "nccl" else ""),
+            "halo_columns": HALO_COLS, "message_records_steady": [c for c in slab.caps[1:-1]],
+            "bytes_sent_per_exchange_rank0": bytes_per_exchange,
+        },
+        "workload_text": workload_text(kind, n_total, rows, params),
+    }
+    del slab
+    return out
+
+
+def main_ranks(args, world, rank, local_rank):
+    """N > 1 under torch.distributed (one rank per GPU)."""
+    import torch
+    import torch.distributed as dist
+
+    share = os.environ.get("SPH_BENCH_SHARE_GPU") == "1"  # rehearsal on a one-GPU box: every rank on device 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if share:
+        local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (SPH_BENCH_SHARE_GPU=1 rehearses the protocol with every "
+                         "slab on device 0)" % (world, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("SPH_BENCH_BACKEND", "gloo" if share else "nccl")  # RCCL refuses two ranks on one GPU
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    name = args.workload or "dam16m"
+    scaling = args.scaling or ("strong" if args.workload is None else "weak")
+    reb = int(os.environ.get("SPH_BENCH_REBALANCE", str(args.rebalance_every)))
+    head = run_slabs(name, scaling, args.steps, args.warmup, reb, local_rank, rank, world)
+    extras = {}
+    if not args.no_extra_scenes and args.workload is None:
+        # configs[4]: 8M particles per GPU, weak scaling (fewer steps: a bounded addition to the run)
+        st = max(args.steps // 2, 5)
+        try:
+            r = run_slabs("dam8m", "weak", st, max(args.warmup // 2, 2), reb, local_rank, rank, world)
+            if rank == 0:
+                r["roofline"] = {k: r["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms")}
+                extras["dam8m_per_gpu_weak"] = r
+        except Exception as e:  # an extra must not take the headline down (every rank fails alike: sizes are global)
+            if rank == 0:
+                extras["dam8m_per_gpu_weak"] = {"error": str(e)}
+    if rank == 0:
+        out = {
+            "metric": "particle-updates/sec (full SPH step)", "value": head["value"], "unit": "particle-updates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": head["workload_text"], "name": name, "particles": head["particles"], "grid": head["grid"],
+                "parallelism": "x-slabs x%d, 2-column ghost halo + migration, one rank per GPU (torch.distributed)" % world,
+                "driver": "c10d", "slabs": head["slabs"],
+                "semantics": "snapshot (Jacobi) neighbour velocities, as SPH/MPI_sph.cpp",
+            },
+            "roofline": head["roofline"], "roofline_valu": None,
+            "phases_ms_per_step": head["phases_ms_per_step_rank0"],
+            "pair_interactions_per_s": head["pair_interactions_per_s"], "mean_neighbors": head["mean_neighbors"],
+            "ups": args.steps / (head["ms_per_step"] * 1e-3 * args.steps),
+        }
+        if not args.no_extra_scenes and scaling == "strong":
+            # the same scene on ONE GPU (rank 0's), for the strong-scaling ratio and the fp32-vector roofline of the kernel
+            try:
+                one = run_single(name, max(args.steps // 4, 5), 3, local_rank)
+                extras[name + "_1gpu"] = brief(one)
+                out["roofline_valu"] = one["roofline_valu"]
+                if out["roofline_valu"]:
+                    out["roofline_valu"]["note"] = "measured on the single-GPU run of the same scene (extra_scenes.%s_1gpu)" % name
+            except Exception as e:
+                extras[name + "_1gpu"] = {"error": str(e)}
+        if extras:
+            out["extra_scenes"] = extras
+        if not args.no_cpu_baseline:
+            base, extra = cpu_baseline()
+            out["cpu_baseline"] = base
+            out.update(extra)
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ---- N > 1 in ONE process: the C++ driver libsph_mg.so --------------------------------------------------------------
+def main_mg(args):
+    import numpy as np
+    import torch
+
+    from sph_amd import scenes
+    from sph_amd.mg import MultiGpuSolver
+
+    world = args.gpus
+    share = os.environ.get("SPH_BENCH_SHARE_GPU") == "1"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if not share and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d --driver mg: only %d GPU(s) visible (SPH_BENCH_SHARE_GPU=1 rehearses the protocol "
+                         "with every slab on device 0)" % (world, torch.cuda.device_count()))
+    devices = [0] * world if share else list(range(world))
+    reb = int(os.environ.get("SPH_BENCH_REBALANCE", str(args.rebalance_every)))
+
+    def run(name, scaling, steps, warmup):
+        kind, cols, rows = WORKLOADS[name]
+        total_cols = cols * world if scaling == "weak" else cols
+        if kind == "dam":
+            params, n_total, _, make_local = scenes.dam_break_sharded(total_cols, rows)
+        else:
+            params, n_total, _, make_local = scenes.uniform_box_sharded(total_cols, rows)
+        from sph_amd import lib as _lib
+
+        drv = _lib.derive(params)
+        a, ids = make_local(0, drv.nx, drv)
+        full = np.zeros(n_total, a.dtype)
+        full[ids] = a
+        del a, ids
+        with MultiGpuSolver(params, full, devices=devices) as m:
+            del full
+            counts_start = m.counts()
+            m.step(warmup, rebalance_every=reb)
+            m.synchronize()
+            r0 = m.rebalances
+            t0 = time.perf_counter()
+            m.step(steps, rebalance_every=reb)
+            m.synchronize()
+            elapsed = time.perf_counter() - t0
+            hs = m.halo_stats()
+            return {
+                "workload": name, "scaling": scaling, "particles": n_total, "grid": [drv.nx, drv.ny], "steps": steps, "warmup": warmup,
+                "value": n_total * steps / elapsed, "unit": "particle-updates/s", "ms_per_step": elapsed / steps * 1e3,
+                "slabs": {"bounds": m.bounds(), "particles_per_rank_start": counts_start, "particles_per_rank_end": m.counts(),
+                          "rebalance_every": reb, "rebalances": m.rebalances - r0, "transport": m.transport,
+                          "bytes_sent_per_exchange_per_slab": hs["bytes_per_exchange_per_slab"],
+                          "message_records_steady_max": hs["max_message_records"]},
+                "workload_text": workload_text(kind, n_total, rows, params),
+            }
+
+    name = args.workload or "dam16m"
+    scaling = args.scaling or ("strong" if args.workload is None else "weak")
+    head = run(name, scaling, args.steps, args.warmup)
+    out = {
+        "metric": "particle-updates/sec (full SPH step)", "value": head["value"], "unit": "particle-updates/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": head["workload_text"], "name": name, "particles": head["particles"], "grid": head["grid"],
+                   "parallelism": "x-slabs x%d, 2-column ghost halo + migration, ONE process (libsph_mg.so: ncclCommInitAll, one "
+                                  "enqueue thread per slab)" % world,
+                   "driver": "mg", "slabs": head["slabs"], "semantics": "snapshot (Jacobi) neighbour velocities, as SPH/MPI_sph.cpp"},
+    }
+    extras = {}
+    if not args.no_extra_scenes and args.workload is None:
+        try:
+            extras["dam8m_per_gpu_weak"] = run("dam8m", "weak", max(args.steps // 2, 5), max(args.warmup // 2, 2))
+        except Exception as e:
+            extras["dam8m_per_gpu_weak"] = {"error": str(e)}
+    if not args.no_extra_scenes and scaling == "strong":
+        try:
+            one = run_single(name, max(args.steps // 4, 5), 3, devices[0])
+            extras[name + "_1gpu"] = brief(one)
+            # (the C++ driver exposes no per-kernel events: the kernel's rooflines are those of the single-GPU run)
+            out["roofline"] = one["roofline"]
+            out["roofline"]["note"] = "measured on the single-GPU run of the same scene (extra_scenes.%s_1gpu). " % name + out["roofline"]["note"]
+            out["roofline_valu"] = one["roofline_valu"]
+        except Exception as e:
+            extras[name + "_1gpu"] = {"error": str(e)}
+    if extras:
+        out["extra_scenes"] = extras
+    if not args.no_cpu_baseline:
+        base, extra = cpu_baseline()
+        out["cpu_baseline"] = base
+        out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+# ---- N = 1 ----------------------------------------------------------------------------------------------------------
+def main_single(args):
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    device = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(device)
+    name = args.workload or "dam1m"
+    kind, cols, rows = WORKLOADS[name]
+    head = run_single(name, args.steps, args.warmup, device, repeats=args.repeats)
+    out = {
+        "metric": "particle-updates/sec (full SPH step)", "value": head["value"], "unit": "particle-updates/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "2D %s, %d particles (%d x %d lattice at spacing H/4, box %.1f x %.1f, sph.h constants), fp32" % (
+                "dam-break" if kind == "dam" else "uniform box filled wall to wall", head["particles"], head["particles"] // rows, rows,
+                head["box"][0], head["box"][1]),
+            "name": name, "particles": head["particles"], "grid": head["grid"], "parallelism": "single GPU",
+            "semantics": "snapshot (Jacobi) neighbour velocities, as SPH/MPI_sph.cpp",
+        },
+        "roofline": head["roofline"], "roofline_valu": head["roofline_valu"],
+        "phases_ms_per_step": head["phases_ms_per_step"],
+        "pair_interactions_per_s": head["pair_interactions_per_s"], "mean_neighbors": head["mean_neighbors"],
+        "ups": args.steps / (head["ms_per_step"] * 1e-3 * args.steps), "tile_rounds": head["tile_rounds"],
+    }
+    for k in ("repeats", "value_median", "value_min", "value_max", "spread"):
+        if k in head:
+            out[k] = head[k]
+    if not args.no_extra_scenes:
+        # the other single-GPU scenes of BASELINE.json (configs[2], the scene of configs[3]) and the headline scene
+        # after 1000 untimed steps (collapsed column, cells up to twice their initial population), same run
+        extras = {}
+        for key, wl, st, evo in (("dam1m_evolved", name, args.steps, 1000), ("box4m", "box4m", max(args.steps // 2, 5), 0),
+                                 ("dam16m", "dam16m", max(args.steps // 4, 5), 0)):
+            try:
+                extras[key] = brief(run_single(wl, st, max(args.warmup, 3), device, evolve=evo))
+            except Exception as e:  # an extra must not take the headline down
+                extras[key] = {"error": str(e)}
+        out["extra_scenes"] = extras
+    if not args.no_cpu_baseline:
+        base, extra = cpu_baseline()
+        out["cpu_baseline"] = base
+        out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (torch.distributed.run)
+    BEFORE this process touches the GPU, relay their output, exit with their code."""
+    import torch  # (importing torch and counting devices do not initialise the GPU)
+
+    share = os.environ.get("SPH_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if have < args.gpus and not share:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; SPH_BENCH_SHARE_GPU=1 rehearses the protocol with every slab "
+                         "on device 0" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 16)))))  # (the launcher would set 1: the CPU baseline needs cores)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rc = subprocess.call(cmd, env=env)
+    raise SystemExit(rc)
 
 
 def main():
@@ -182,212 +622,39 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=None)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: dam1m at N = 1 (configs[1]); dam16m split over the GPUs at N > 1 (configs[3])")
     ap.add_argument("--rebalance-every", type=int, default=100,
                     help="N > 1: steps between two slab rebalances (0: never); also SPH_BENCH_REBALANCE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-scenes", action="store_true",
-                    help="N = 1: skip the extra single-GPU scenes (box4m, dam16m, evolved dam1m) reported beside the headline")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = the workload per GPU (default, the driver's contract); strong = the named workload "
-                    "split over the GPUs (BASELINE configs[3]: --workload dam16m --scaling strong)")
+                    help="skip the extra scenes reported beside the headline (N = 1: box4m, dam16m, evolved dam1m; N > 1: dam8m "
+                    "per GPU weak scaling, the headline scene on one GPU)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: strong = the named workload split over the GPUs (default without --workload: dam16m, "
+                    "BASELINE configs[3]); weak = the named workload per GPU (default with --workload)")
+    ap.add_argument("--driver", choices=["c10d", "mg"], default="c10d",
+                    help="N > 1: c10d = one process per GPU over torch.distributed (sph_amd/slab.py); mg = one process, "
+                    "libsph_mg.so (C++ driver, ncclCommInitAll)")
+    ap.add_argument("--repeats", type=int, default=5, help="N = 1: timed intervals of --steps steps (value = the first; "
+                    "median / min / max over all of them are reported beside it)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus == 1 and (env_world is None or env_world == "1") and os.environ.get("SPH_BENCH_FORCE_SLAB") != "1":
+        return main_single(args)
+    if args.driver == "mg":
+        if env_world not in (None, "1"):
+            raise SystemExit("--driver mg runs all slabs from ONE process: start it without torch.distributed.run")
+        return main_mg(args)
+    if env_world is None:
+        return self_launch(args, sys.argv[1:])
+    world = int(env_world)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    if os.environ.get("SPH_BENCH_SHARE_GPU") == "1":  # debugging on a one-GPU box: every rank on device 0
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-
-    name = args.workload or "dam1m"
-    kind, cols, rows = WORKLOADS[name]
-
-    force_slab = os.environ.get("SPH_BENCH_FORCE_SLAB") == "1"  # exercise the slab path on one GPU
-    if world == 1 and not force_slab:
-        params, a = scenes.dam_break(cols, rows) if kind == "dam" else scenes.uniform_box(cols)
-        n_total = len(a)
-        solver = Solver(params, n_max=n_total, device=local_rank)
-        solver.upload(a)
-        step = lambda k: solver.stepSimulation(nsteps=k)  # noqa: E731
-        sync = lambda: torch.cuda.synchronize()  # noqa: E731
-        barrier = lambda: None  # noqa: E731
-        parallelism = "single GPU"
-        drv = solver.drv
-    else:
-        import torch.distributed as dist
-
-        from sph_amd import lib as _lib
-        from sph_amd.slab import make_hip_slab
-
-        if world == 1:  # SPH_BENCH_FORCE_SLAB without a launcher: a one-rank group
-            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
-                os.environ.setdefault(k, v)
-        backend = os.environ.get("SPH_BENCH_BACKEND", "nccl")  # "gloo": debugging on a one-GPU box (host-staged messages)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-        # weak scaling: the fluid column gets `world` times wider, per-GPU particle count fixed;
-        # strong scaling: the named scene as it is, split into `world` slabs
-        total_cols = cols * world if args.scaling == "weak" else cols
-        sharded = scenes.dam_break_sharded if kind == "dam" else scenes.uniform_box_sharded
-        params, n_total, hist_fn, make_local = sharded(total_cols, rows)
-        drv = _lib.derive(params)
-        solver = make_hip_slab(params, make_local, local_rank, hist=hist_fn(drv))
-        # the dam collapses to the right: slabs are re-balanced (and the halo messages re-sized) every K steps
-        rebalance_every = int(os.environ.get("SPH_BENCH_REBALANCE", str(args.rebalance_every)))
-        step = lambda k: solver.run(k, rebalance_every)  # noqa: E731
-        sync = lambda: torch.cuda.synchronize()  # noqa: E731
-        barrier = lambda: dist.barrier()  # noqa: E731
-        parallelism = "x-slabs x%d, 2-column ghost halo + migration over RCCL" % world
-
-    step(args.warmup)
-    sync()
-    slabbed = world > 1 or force_slab
-    inner = solver.solver if slabbed else solver
-    # HIP events around the dominant kernel only (events between the small back-to-back kernels
-    # of the sort cost ~10 % of a step); the full per-phase breakdown is taken after the timed region
-    # (not on slabs: a profiled slab step runs its two force passes back to back instead of side by side, and the
-    # events would time the boundary pass only; the slab line takes the kernel time from the breakdown steps below)
-    if not slabbed:
-        inner.set_profiling_phases(["force"])
-        inner.set_profiling_period(FORCE_SAMPLE_PERIOD)
-    inner.reset_phase_times()
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    step(args.steps)
-    sync()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    phases = inner.phase_times()
-    inner.set_profiling(False)
-    # per-phase breakdown: a few extra steps with every phase bracketed (not part of `value`)
-    inner.set_profiling_period(1)
-    inner.set_profiling(True)
-    inner.reset_phase_times()
-    step(5)
-    sync()
-    breakdown = inner.phase_times()
-    inner.set_profiling(False)
-    if slabbed:
-        phases = breakdown
-    if slabbed:
-        solver.check()  # raises if a halo buffer / the particle capacity overflowed during the asynchronous steps
-    n_local = inner.n
-    if world > 1:
-        # particles this rank integrates per step (ghosts excluded): what the force kernel's
-        # algorithmic bytes are counted on
-        n_local = n_total // world
-
-    if world > 1:
-        import torch.distributed as dist
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # neighbour statistics, off the timed path
-    if slabbed:
-        inner.drop_ghosts()
-        inner.set_owned_columns(0, drv.nx)  # count over this rank's own particles only (edge pairs are missed)
-    inner.computeDensityPressure()
-    pairs_local = inner.pair_count()
-    cand_local = stencil_candidates(inner, drv) if world == 1 else 0
-    if world > 1:
-        t = torch.tensor([pairs_local], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t)
-        pairs = float(t.item())
-    else:
-        pairs = float(pairs_local)
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n_total * args.steps / elapsed
-        f_ms, f_k = phases["force"]
-        # per step, not per launch: a slab step with neighbours runs the pass as two launches (boundary columns, interior)
-        # single GPU: the sampled launches of the timed region; slabs: per step over the 5 breakdown steps (two launches each)
-        force_avg_s = (f_ms / max(min(f_k, 5) if slabbed else f_k, 1)) * 1e-3
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(name, {}).get("k_force_bytes_per_launch")
-            except Exception:
-                traffic = None
-        valu = None  # what actually bounds the kernel: VALU issue (PMC of the committed profile, informational)
-        try:
-            src = json.load(open(tf)).get(name, {}).get("source")
-            pm = json.load(open(os.path.join(ROOT, src)))
-            kf = [v for k, v in pm.items() if k.startswith("k_force<true")][0]
-            valu = {"cycles_per_wave_instruction": kf.get("valu_cycles_per_wave_instr"), "lane_utilisation": kf.get("valu_lane_utilisation"),
-                    "wave_instructions_per_launch": kf.get("SQ_INSTS_VALU"), "source": src}
-        except Exception:
-            valu = None
-        roof_hbm, roof_fp32 = force_rooflines(n_local, force_avg_s, pairs_local, cand_local, traffic, valu)
-        out = {
-            "metric": "particle-updates/sec (full SPH step)",
-            "value": value,
-            "unit": "particle-updates/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "2D %s, %%d particles (%%d x %%d lattice at spacing H/4, box %%.1f x %%.1f, sph.h constants), fp32"
-                % ("dam-break" if kind == "dam" else "uniform box filled wall to wall")
-                % (n_total, n_total // rows, rows, params.xmax - params.xmin, params.ymax - params.ymin),
-                "name": name,
-                "particles": n_total,
-                "grid": [drv.nx, drv.ny],
-                "parallelism": parallelism,
-                "rebalance_every": (rebalance_every if (world > 1 or force_slab) else None),
-                "rebalances": (solver.rebalances if (world > 1 or force_slab) else None),
-                "semantics": "snapshot (Jacobi) neighbour velocities, as SPH/MPI_sph.cpp",
-            },
-            "roofline": roof_hbm,
-            "roofline_valu": roof_fp32 if world == 1 else None,
-            "phases_ms_per_step": {k: v[0] / 5 for k, v in breakdown.items()},
-            "pair_interactions_per_s": 2.0 * pairs * args.steps / elapsed,  # density + force passes
-            "mean_neighbors": pairs / max(n_total, 1),
-            "ups": args.steps / elapsed,
-        }
-        if world == 1 and not force_slab and not args.no_extra_scenes:
-            # the other single-GPU scenes of BASELINE.json (configs[2], the scene of configs[3]) and the headline scene
-            # after 1000 untimed steps (collapsed column, cells up to twice their initial population), same run
-            del solver
-            extras = {}
-            for key, wl, st, evo in (("dam1m_evolved", name, args.steps, 1000), ("box4m", "box4m", max(args.steps // 2, 5), 0),
-                                     ("dam16m", "dam16m", max(args.steps // 4, 5), 0)):
-                try:
-                    extras[key] = run_single(wl, st, max(args.warmup, 3), local_rank, evolve=evo)
-                except Exception as e:  # an extra must not take the headline down
-                    extras[key] = {"error": str(e)}
-            out["extra_scenes"] = extras
-        if not args.no_cpu_baseline and world == 1:
-            base, extra = cpu_baseline(world)
-            out["cpu_baseline"] = base
-            out.update(extra)
-        print(json.dumps(out), flush=True)
-
-    if slabbed:
-        import torch.distributed as dist
-
-        dist.barrier()
-        dist.destroy_process_group()
+    return main_ranks(args, world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")))
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-typedef struct SphMg SphMg; /* opaque: one SphCtx, two streams and four message buffers per GPU, one RCCL communicator each */
+typedef struct SphMg SphMg; /* opaque: one SphCtx, a communication stream and four message buffers per GPU, one RCCL communicator each */
 
 /* Distributes the n particles (28-byte records, reference index order = particle id) over n_gpus x-slabs with about
  * equal particle counts, one per HIP device devices[g] (NULL: 0 .. n_gpus-1).  Replaces the MPI_Bcast of the whole
@@ -24,7 +24,9 @@ typedef struct SphMg SphMg; /* opaque: one SphCtx, two streams and four message 
  * not be divisible by n_gpus.  SPHHIP_EINVAL if the grid has fewer than 3 columns per slab.
  * Transport: RCCL send/recv when every slab has its own device; device-to-device hipMemcpyAsync on the
  * communication streams when slabs share a device (several slabs on one GPU: what a one-GPU box can run of the
- * whole protocol) or when SPHMG_TRANSPORT=copy asks for it. */
+ * whole protocol) or when SPHMG_TRANSPORT=copy asks for it.  With RCCL the peer connections are set up here (one
+ * header-sized exchange per neighbour pair), so a transport that does not work fails this call.  If a slab fails
+ * during an RCCL run the communicators are aborted and every later call but sphmg_destroy returns SPHHIP_ESTATE. */
 int sphmg_create(const SphParams* p, const void* aos28, int n, int n_gpus, const int* devices, SphMg** out);
 /* nsteps steps of serial_stepSimulation (SPH/sph.cpp:166-171) on all slabs; per step and direction ONE
  * nearest-neighbour message (ghost columns + migrants) instead of mpi_computeStep's four Allgathers
@@ -41,6 +43,13 @@ int sphmg_download(SphMg* mg, void* aos28, int n);
 int sphmg_counts(SphMg* mg, int* per_gpu);
 int sphmg_bounds(SphMg* mg, int* bounds);
 int sphmg_rebalance_count(SphMg* mg);
+/* What the exchanges shipped so far: their number, the average bytes one slab sent per exchange (both directions,
+ * headers included: messages travel at a size fixed per slab boundary from the global column histogram -- 1.25 x the
+ * population of the halo columns, SPHMG_HALO_MARGIN -- not at their record count) and the largest steady-state
+ * message in records.  Any pointer may be NULL. */
+int sphmg_halo_stats(SphMg* mg, long long* exchanges, double* bytes_per_exchange_per_slab, int* max_message_records);
+/* "rccl", "copy" (slabs sharing a device / SPHMG_TRANSPORT=copy) or "none" (one slab). */
+const char* sphmg_transport(SphMg* mg);
 int sphmg_destroy(SphMg* mg);
 const char* sphmg_last_error(void);
 /* Loopback check of the transport on one device: a grouped ncclSend / ncclRecv of `bytes` bytes to the rank itself,

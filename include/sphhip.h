@@ -103,7 +103,9 @@ int sphhip_derive(const SphParams* p, SphDerived* out);
 int sphhip_create(const SphParams* p, int n_max, int device, SphCtx** out);
 /* Replaces cleanupSimulation (SPH/sph.cu:275-280). */
 int sphhip_destroy(SphCtx* ctx);
-/* Run on a caller-owned HIP stream (hipStream_t as void*; NULL => the context's own stream). */
+/* Run on a caller-owned HIP stream (hipStream_t as void*; NULL => the context's own stream).  The context's side
+ * stream (interior force pass of a split slab step) is re-created at that stream's priority: the two wait for
+ * each other, and a stream that another one waits for must never have the lower priority. */
 int sphhip_set_stream(SphCtx* ctx, void* hip_stream);
 /* Run on the device's default (null) stream, e.g. to be ordered with a framework that works on
  * it (the context's own stream is non-blocking and does not synchronise with the null stream). */
@@ -222,20 +224,22 @@ int sphhip_set_owned_columns(SphCtx* ctx, int col_lo, int col_hi);
 int sphhip_pack_halo(SphCtx* ctx, int send_hi_left, int send_lo_right,
                      void* d_left, int cap_left, int* n_left,
                      void* d_right, int cap_right, int* n_right);
-/* The same split WITHOUT a host synchronisation, for a fixed-size exchange: d_msg_left /
- * d_msg_right are device buffers of (cap + 1) 20-byte records whose record 0 is a header (word 0 =
- * number of records that follow); either may be NULL (no neighbour on that side).  The messages
- * can be sent as they are, stream-ordered behind this call.  From here on the particle count is
+/* The same split WITHOUT a host synchronisation, for an exchange whose size the host fixes beforehand:
+ * d_msg_left / d_msg_right are device buffers of (cap_left + 1) / (cap_right + 1) 20-byte records whose
+ * record 0 is a header (word 0 = number of records that follow); either may be NULL (no neighbour on
+ * that side).  A message can be sent as it is -- its first (cap + 1) records -- stream-ordered behind
+ * this call; sender and receiver agree on cap per slab boundary (both derive it from the global column
+ * histogram), so no count has to travel first.  From here on the particle count is
  * known on the device only (kernels read it there; launches are sized by the capacity) until a
  * call that needs it on the host synchronises, e.g. sphhip_sync_counts, sphhip_download. */
-int sphhip_pack_halo_async(SphCtx* ctx, int send_hi_left, int send_lo_right, void* d_msg_left, void* d_msg_right,
-                           int cap);
+int sphhip_pack_halo_async(SphCtx* ctx, int send_hi_left, int send_lo_right, void* d_msg_left, int cap_left,
+                           void* d_msg_right, int cap_right);
 /* Appends the records of a received fixed-size message (header + up to cap records, device
  * memory), reading the count from its header on the device: no host synchronisation. */
 int sphhip_append_message(SphCtx* ctx, const void* d_msg, int cap);
 /* The messages from both neighbours in one launch: a first, b behind it (the same result as two
  * sphhip_append_message calls in that order); either may be NULL. */
-int sphhip_append_messages(SphCtx* ctx, const void* d_msg_a, const void* d_msg_b, int cap);
+int sphhip_append_messages(SphCtx* ctx, const void* d_msg_a, int cap_a, const void* d_msg_b, int cap_b);
 /* Synchronises the stream, returns the particle count (n may be NULL) and reports, as
  * SPHHIP_ECAPACITY, any overflow (halo message buffer, context capacity) that happened in the
  * asynchronous calls since the last synchronisation. */
@@ -269,6 +273,8 @@ enum {
     SPHHIP_PH_DENSITY,
     SPHHIP_PH_FORCE,      /* force (+ fused integrate inside sphhip_step) */
     SPHHIP_PH_INTEGRATE,  /* stand-alone integrate */
+    SPHHIP_PH_FORCE_INTERIOR, /* split slab step: the interior columns' force pass, which runs on the context's side
+                               * stream beside the boundary columns' pass (that one is counted under SPHHIP_PH_FORCE) */
     SPHHIP_PH_COUNT
 };
 /* When enabled, every phase is bracketed by HIP events on the context's stream. */

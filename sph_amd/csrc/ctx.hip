@@ -29,7 +29,7 @@ static inline bool phase_timed(const SphCtx* c, int ph) {
     return c->profiling && ((c->profile_mask >> ph) & 1u) && (c->profile_period <= 1 || c->profile_step == 0 || (c->profile_step - 1) % c->profile_period == 0);  // steps 1, 1 + period, ...
 }
 
-void sph_phase_begin(SphCtx* c, int ph) {
+void sph_phase_begin(SphCtx* c, int ph, hipStream_t on) {
     if (!phase_timed(c, ph)) return;
     PhaseTimer& t = c->timer;
     if (t.used[ph] == t.start[ph].size()) {
@@ -38,14 +38,17 @@ void sph_phase_begin(SphCtx* c, int ph) {
         t.start[ph].push_back(a);
         t.stop[ph].push_back(b);
     }
-    (void)hipEventRecord(t.start[ph][t.used[ph]], c->stream);  // timing only: a failure shows up as a missing sample
+    (void)hipEventRecord(t.start[ph][t.used[ph]], on);  // timing only: a failure shows up as a missing sample
 }
 
-void sph_phase_end(SphCtx* c, int ph) {
+void sph_phase_begin(SphCtx* c, int ph) { sph_phase_begin(c, ph, c->stream); }
+void sph_phase_end(SphCtx* c, int ph) { sph_phase_end(c, ph, c->stream); }
+
+void sph_phase_end(SphCtx* c, int ph, hipStream_t on) {
     if (!phase_timed(c, ph)) return;
     PhaseTimer& t = c->timer;
     if (t.used[ph] >= t.stop[ph].size()) return;
-    (void)hipEventRecord(t.stop[ph][t.used[ph]], c->stream);
+    (void)hipEventRecord(t.stop[ph][t.used[ph]], on);
     t.used[ph]++;
 }
 
@@ -312,8 +315,12 @@ extern "C" int sphhip_create(const SphParams* p, int n_max, int device, SphCtx**
     ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     {
-        // (Default priority on purpose: with the lowest priority, four slabs sharing one GPU -- sixteen streams on the
-        // four hardware queues of a process -- stopped making progress in tests/test_gpu_mg.py.)
+        // Stream invariant ("Streams and progress"): a stream that another stream waits for never has
+        // a lower priority than the waiter.  The side stream and the context's stream wait for each other (ev_fork,
+        // ev_join), so they have the SAME priority -- here the default, and sphhip_set_stream re-creates the side stream
+        // at the priority of a caller's stream.  (Round 2 tried the lowest priority for the side stream: four slabs on
+        // one GPU stopped making progress, the higher-priority queues parked on barrier packets that only the starved
+        // stream's kernel could release.)
         ok(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
         ok(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         ok(hipEventCreateWithFlags(&c->ev_pace[0], hipEventDisableTiming));
@@ -383,18 +390,34 @@ extern "C" int sphhip_destroy(SphCtx* c) {
     return SPHHIP_OK;
 }
 
+// Keeps the stream invariant of sphhip_create: the side stream at the priority of the stream it forks from / joins.
+static int side_stream_follow(SphCtx* c) {
+    if (!c->side_stream) return SPHHIP_OK;
+    int want = 0, have = 0;
+    HIP_TRY(hipStreamGetPriority(c->stream, &want));  // (the null stream reports the default priority)
+    HIP_TRY(hipStreamGetPriority(c->side_stream, &have));
+    if (want == have) return SPHHIP_OK;
+    HIP_TRY(hipStreamSynchronize(c->side_stream));
+    HIP_TRY(hipStreamDestroy(c->side_stream));
+    c->side_stream = nullptr;
+    HIP_TRY(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, want));
+    return SPHHIP_OK;
+}
+
 extern "C" int sphhip_set_stream(SphCtx* c, void* s) {
     if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
-    return SPHHIP_OK;
+    return side_stream_follow(c);
 }
 
 extern "C" int sphhip_use_default_stream(SphCtx* c) {
     if (!c) return fail(SPHHIP_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = nullptr;  // the legacy default (null) stream
-    return SPHHIP_OK;
+    return side_stream_follow(c);
 }
 
 extern "C" int sphhip_get_stream(SphCtx* c, void** s) {
@@ -1048,12 +1071,14 @@ __global__ __launch_bounds__(256) void k_pack_boundary(DevConsts c, const float2
                                                         const int* __restrict__ cell_start, int left_lo_cell,
                                                         int left_hi_cell, int right_lo_cell, int right_hi_cell,
                                                         int send_hi_left, int send_lo_right, HaloRec* __restrict__ left,
-                                                        HaloRec* __restrict__ right, int cap, int* __restrict__ msg_cnt,
-                                                        int* __restrict__ ticket, int* __restrict__ err) {
+                                                        int cap_left, HaloRec* __restrict__ right, int cap_right,
+                                                        int* __restrict__ msg_cnt, int* __restrict__ ticket,
+                                                        int* __restrict__ err) {
     __shared__ int s_cnt[4];
     __shared__ int s_base;
     const int side = blockIdx.x / PACK_BLOCKS, b = blockIdx.x % PACK_BLOCKS;
     HaloRec* out = side ? right : left;
+    const int cap = side ? cap_right : cap_left;
     if (out) {
         const int lo = cell_start[side ? right_lo_cell : left_lo_cell], hi = cell_start[side ? right_hi_cell : left_hi_cell];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1092,8 +1117,8 @@ __global__ __launch_bounds__(256) void k_pack_boundary(DevConsts c, const float2
         if (done == (int)gridDim.x - 1) {
             __threadfence();
             const int nl = atomicExch(&msg_cnt[0], 0), nr = atomicExch(&msg_cnt[1], 0);
-            if (left) left[0] = {__int_as_float(nl < cap ? nl : cap), 0.0f, 0.0f, 0.0f, 0u};
-            if (right) right[0] = {__int_as_float(nr < cap ? nr : cap), 0.0f, 0.0f, 0.0f, 0u};
+            if (left) left[0] = {__int_as_float(nl < cap_left ? nl : cap_left), 0.0f, 0.0f, 0.0f, 0u};
+            if (right) right[0] = {__int_as_float(nr < cap_right ? nr : cap_right), 0.0f, 0.0f, 0.0f, 0u};
             atomicExch(ticket, 0);
         }
     }
@@ -1115,10 +1140,10 @@ static int split_impl(SphCtx* c, int send_hi_left, int send_lo_right, int keep_l
     return SPHHIP_OK;
 }
 
-extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_right, void* d_msg_left,
-                                      void* d_msg_right, int cap) {
+extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_right, void* d_msg_left, int cap_left,
+                                      void* d_msg_right, int cap_right) {
     NEED_STATE_MIDSTEP(c);
-    if (cap < 0) return fail(SPHHIP_EINVAL, "sphhip_pack_halo_async: negative capacity");
+    if (cap_left < 0 || cap_right < 0) return fail(SPHHIP_EINVAL, "sphhip_pack_halo_async: negative capacity");
     HaloRec* l = (HaloRec*)d_msg_left;
     HaloRec* r = (HaloRec*)d_msg_right;
     // record 0 of a message is its header (word 0 = record count); records follow from row 1
@@ -1136,7 +1161,7 @@ extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_r
         const int r_lo = c->col_hi - reach > c->col_lo ? c->col_hi - reach : c->col_lo;
         hipLaunchKernelGGL(k_pack_boundary, dim3(2 * PACK_BLOCKS), dim3(256), 0, c->stream, c->dc, c->pos, c->vel, c->idv,
                            c->cell_start, c->col_lo * ny, l_hi * ny, r_lo * ny, c->col_hi * ny, send_hi_left, send_lo_right,
-                           l, r, cap, c->counters + SPH_MSG_COUNT_SLOT, c->counters + SPH_MSG_TICKET_SLOT, c->d_err);
+                           l, cap_left, r, cap_right, c->counters + SPH_MSG_COUNT_SLOT, c->counters + SPH_MSG_TICKET_SLOT, c->d_err);
         LAUNCH_CHECK();
         c->pending_drop = true;
         c->grid_valid = false;  // positions have moved since the sort (the fused step leaves it false anyway)
@@ -1148,8 +1173,8 @@ extern "C" int sphhip_pack_halo_async(SphCtx* c, int send_hi_left, int send_lo_r
         return fail(SPHHIP_ESTATE, "sphhip_pack_halo_async between sphhip_step_begin and sphhip_step_finish: the send ranges "
                                    "exceed the halo (only the boundary-only pack may run there)");
     return split_enqueue(c, l ? send_hi_left : -1, r ? send_lo_right : 0x7fffffff, c->col_lo - SPHHIP_HALO_COLS,
-                         c->col_hi + SPHHIP_HALO_COLS, l ? l + 1 : nullptr, l ? cap : 0, l ? (int*)l : c->counters,
-                         r ? r + 1 : nullptr, r ? cap : 0, r ? (int*)r : c->counters + 1);
+                         c->col_hi + SPHHIP_HALO_COLS, l ? l + 1 : nullptr, l ? cap_left : 0, l ? (int*)l : c->counters,
+                         r ? r + 1 : nullptr, r ? cap_right : 0, r ? (int*)r : c->counters + 1);
 }
 
 extern "C" int sphhip_pack_halo(SphCtx* c, int send_hi_left, int send_lo_right, void* d_left, int cap_left,
@@ -1249,7 +1274,7 @@ extern "C" int sphhip_append_message(SphCtx* c, const void* d_msg, int cap) {
 
 // Two received messages in one launch (a slab step appends one from each side: two launches at the ~4.5 us floor
 // each became one).  Message a lands behind the current particles, message b behind message a.
-__global__ __launch_bounds__(256) void k_append2(const HaloRec* __restrict__ msg_a, const HaloRec* __restrict__ msg_b, int cap,
+__global__ __launch_bounds__(256) void k_append2(const HaloRec* __restrict__ msg_a, int cap_a, const HaloRec* __restrict__ msg_b, int cap_b,
                                                   const int* __restrict__ n_in, int* __restrict__ n_out, int n_max,
                                                   int* __restrict__ err, float2* __restrict__ pos, float2* __restrict__ vel,
                                                   float* __restrict__ rho, float* __restrict__ prs,
@@ -1258,13 +1283,13 @@ __global__ __launch_bounds__(256) void k_append2(const HaloRec* __restrict__ msg
     const int at = *n_in;
     int ca = *(const int*)msg_a, cb = *(const int*)msg_b;
     int flag = 0;
-    if (ca < 0 || ca > cap) {
+    if (ca < 0 || ca > cap_a) {
         flag |= SPH_ERR_MSG_BAD;
-        ca = ca < 0 ? 0 : cap;
+        ca = ca < 0 ? 0 : cap_a;
     }
-    if (cb < 0 || cb > cap) {
+    if (cb < 0 || cb > cap_b) {
         flag |= SPH_ERR_MSG_BAD;
-        cb = cb < 0 ? 0 : cap;
+        cb = cb < 0 ? 0 : cap_b;
     }
     if (at + ca > n_max) {
         flag |= SPH_ERR_CAPACITY;
@@ -1278,8 +1303,8 @@ __global__ __launch_bounds__(256) void k_append2(const HaloRec* __restrict__ msg
         *n_out = at + ca + cb;
         if (flag) atomicOr(err, flag);
     }
-    const bool second = t >= cap;  // threads [0, cap): message a; [cap, 2 cap): message b
-    const int i = second ? t - cap : t;
+    const bool second = t >= cap_a;  // threads [0, cap_a): message a; [cap_a, cap_a + cap_b): message b
+    const int i = second ? t - cap_a : t;
     if (i >= (second ? cb : ca)) return;
     const HaloRec r = (second ? msg_b : msg_a)[1 + i];
     const int dst = at + (second ? ca : 0) + i;
@@ -1290,16 +1315,16 @@ __global__ __launch_bounds__(256) void k_append2(const HaloRec* __restrict__ msg
     idv[dst] = r.idv;
 }
 
-extern "C" int sphhip_append_messages(SphCtx* c, const void* d_msg_a, const void* d_msg_b, int cap) {
+extern "C" int sphhip_append_messages(SphCtx* c, const void* d_msg_a, int cap_a, const void* d_msg_b, int cap_b) {
     if (!c) return fail(SPHHIP_EINVAL, "sphhip_append_messages: null context");
-    if (cap < 0) return fail(SPHHIP_EINVAL, "sphhip_append_messages: negative capacity");
+    if (cap_a < 0 || cap_b < 0) return fail(SPHHIP_EINVAL, "sphhip_append_messages: negative capacity");
     if (!d_msg_a && !d_msg_b) return SPHHIP_OK;
-    if (!d_msg_a || !d_msg_b) return sphhip_append_message(c, d_msg_a ? d_msg_a : d_msg_b, cap);
+    if (!d_msg_a || !d_msg_b) return sphhip_append_message(c, d_msg_a ? d_msg_a : d_msg_b, d_msg_a ? cap_a : cap_b);
     HIP_TRY(hipSetDevice(c->device));
     int* out = n_slot_next(c);
-    int grid = (2 * cap + 255) / 256;
+    int grid = (int)(((long long)cap_a + cap_b + 255) / 256);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_append2, dim3(grid), dim3(256), 0, c->stream, (const HaloRec*)d_msg_a, (const HaloRec*)d_msg_b, cap, c->d_n,
+    hipLaunchKernelGGL(k_append2, dim3(grid), dim3(256), 0, c->stream, (const HaloRec*)d_msg_a, cap_a, (const HaloRec*)d_msg_b, cap_b, c->d_n,
                        out, c->n_max, c->d_err, c->pos, c->vel, c->rho, c->prs, c->idv, c->params.rest_density);
     LAUNCH_CHECK();
     n_advance(c);

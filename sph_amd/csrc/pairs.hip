@@ -1871,15 +1871,18 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     // Slab step in two halves: the boundary columns' pass is a few hundred workgroups, one tile's latency (20 us) of a
     // nearly empty GPU.  So the interior pass is started first, on the side stream behind everything enqueued so
     // far, and the boundary pass runs beside it on the context's stream; sphhip_step_finish only joins.  Same kernels, same tiles, disjoint output slots.  Not while dense
-    // sub-tiles are listed (the two passes would share the list) or phases are being timed.
+    // sub-tiles are listed (the two passes would share the list).  When phases are timed the interior launch is
+    // bracketed on the side stream (SPHHIP_PH_FORCE_INTERIOR), the boundary launch on the context's (SPHHIP_PH_FORCE).
     bool beside = false;
-    if (part == 1 && c->split_concurrent && c->side_stream && !(sink.mode & 1) && !c->profiling) {
+    if (part == 1 && c->split_concurrent && c->side_stream && !(sink.mode & 1)) {
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        sph_phase_begin(c, SPHHIP_PH_FORCE_INTERIOR, c->side_stream);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->side_stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
                            c->cell_start, pout, vout, q, il, ih, 0, 0, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength,
                            c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink, c->d_consts);
         LAUNCH_CHECK();
+        sph_phase_end(c, SPHHIP_PH_FORCE_INTERIOR, c->side_stream);
         HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
         beside = true;
     }

@@ -57,6 +57,9 @@ static_assert(sizeof(HaloRec) == 20, "halo record");
 struct Slab {
     int device = 0;
     SphCtx* ctx = nullptr;
+    // compute = the context's own stream (sphhip_get_stream; not created here: one stream fewer per slab on the
+    // hardware queues of the process); comm_stream carries the transfers.  Both have the default priority -- the
+    // stream invariant of DESIGN.md section 6: no stream that another one waits for has a lower priority than the waiter.
     hipStream_t compute = nullptr, comm_stream = nullptr;
     hipEvent_t packed = nullptr, received = nullptr;
     ncclComm_t comm = nullptr;
@@ -68,7 +71,15 @@ struct Slab {
 struct SphMg {
     SphParams params;
     SphDerived drv;
-    int n = 0, world = 0, cap = 0, rebalances = 0;
+    int n = 0, world = 0, rebalances = 0;
+    // Message sizes in records, per slab boundary g = 1 .. world-1 (entries 0 and world unused): `cap` between two
+    // rebalances, `cap_first` for the first exchange of the next run of steps (after a rebalance: the hand-over of the
+    // columns between the old and the new boundary); cap_alloc = what the four buffers of every slab hold.
+    std::vector<int> cap, cap_first;
+    int cap_alloc = 0;
+    double halo_margin = 1.25;  // SPHMG_HALO_MARGIN
+    bool broken = false;        // a slab failed inside an RCCL run: the communicators were aborted, nothing runs any more
+    long long records_sent = 0, exchanges = 0;  // sum over slabs and exchanges of the records shipped (headers included)
     bool have_halo = false;  // the ghosts of the next step are already appended
     bool threaded = true;         // one host thread per slab enqueues its steps (SPHMG_THREADS=0: one thread drives all slabs)
     bool copy_transport = false;  // messages by hipMemcpyAsync instead of RCCL (slabs sharing a device; SPHMG_TRANSPORT=copy)
@@ -112,10 +123,42 @@ std::vector<int> balanced_bounds(const std::vector<long long>& hist, int world, 
     return b;
 }
 
-int halo_capacity(const std::vector<long long>& hist) {
-    long long m = 0;
-    for (long long v : hist) m = std::max(m, v);
-    return (int)std::max<long long>((long long)(2.5 * HALO * (double)m), 4096);
+// Records per message across every inner boundary between two rebalances: the HALO columns next to the boundary plus
+// the migrants of one step, sized from the fullest column within reach of the boundary (the halo and two columns more
+// on each side) times `margin`.  Every slab derives the same numbers from the same global histogram, so a message
+// travels at a size the host fixes beforehand without a count round trip -- and ships about what is needed (the first
+// version sent 2.5 x HALO x the fullest column of the whole domain, every step).  Same rule as sph_amd/slab.py.
+constexpr int HALO_FLOOR = 1024;
+std::vector<int> steady_caps(const std::vector<long long>& hist, const std::vector<int>& b, double margin, int floor_records) {
+    std::vector<int> caps(b.size(), 0);
+    const int nx = (int)hist.size();
+    for (size_t g = 1; g + 1 < b.size(); g++) {
+        long long m = 0;
+        for (int c = std::max(b[g] - HALO - 2, 0); c < std::min(b[g] + HALO + 2, nx); c++) m = std::max(m, hist[c]);
+        caps[g] = (int)std::max<long long>((long long)(margin * HALO * (double)m), floor_records);
+    }
+    return caps;
+}
+
+// ... and of the FIRST exchange after the boundaries moved from `old` to `now`: it hands over every column between the
+// two besides the halo.  The histogram was taken at the rebalance itself, so its sum over those columns is what the
+// message will hold (+ 1/16 + 256: migrants still with their old owner are counted at their new column).
+std::vector<int> handover_caps(const std::vector<long long>& hist, const std::vector<int>& old, const std::vector<int>& now,
+                               const std::vector<int>& steady) {
+    std::vector<int> caps = steady;
+    const int nx = (int)hist.size();
+    for (size_t g = 1; g + 1 < now.size(); g++) {
+        if (old[g] == now[g]) continue;
+        long long need = 0;
+        for (int c = std::max(std::min(old[g], now[g]) - HALO, 0); c < std::min(std::max(old[g], now[g]) + HALO, nx); c++) need += hist[c];
+        caps[g] = (int)std::max<long long>(steady[g], need + need / 16 + 256);
+    }
+    return caps;
+}
+
+int floor_records() {
+    const char* e = std::getenv("SPHMG_HALO_FLOOR");
+    return e && std::atoi(e) > 0 ? std::atoi(e) : HALO_FLOOR;
 }
 
 struct HostTimer {
@@ -131,7 +174,9 @@ struct HostTimer {
 };
 const char* const HOST_PHASE[6] = {"pack", "exchange", "append", "step_begin", "step_finish", "step"};
 
+// Makes the four message buffers of every slab hold (cap + 1) records (grow only; the callers have synchronised).
 int alloc_messages(SphMg* mg, int cap) {
+    if (cap <= mg->cap_alloc) return SPHHIP_OK;
     const size_t bytes = sizeof(HaloRec) * ((size_t)cap + 1);
     for (Slab& s : mg->slabs) {
         HIP_OK(hipSetDevice(s.device));
@@ -141,9 +186,11 @@ int alloc_messages(SphMg* mg, int cap) {
             HIP_OK(hipMemset(*p, 0, bytes));
         }
     }
-    mg->cap = cap;
+    mg->cap_alloc = cap;
     return SPHHIP_OK;
 }
+
+size_t msg_bytes(int cap) { return sizeof(HaloRec) * ((size_t)cap + 1); }
 
 int set_bounds(SphMg* mg, const std::vector<int>& b) {
     mg->bounds = b;
@@ -159,9 +206,10 @@ int set_bounds(SphMg* mg, const std::vector<int>& b) {
 // One fixed-size message per direction (header + records) between x-neighbours, all slabs in one group, on the
 // communication streams, ordered behind the packs by events; the compute streams wait for `received` before they
 // append.  Replaces MPI_Allgather x 4 per step (MPI_sph.cpp:144-147,163-166).
-int exchange(SphMg* mg) {
+int exchange_all(SphMg* mg, const std::vector<int>& cap) {
     HostTimer ht(mg, 1);
-    const size_t bytes = sizeof(HaloRec) * ((size_t)mg->cap + 1);
+    for (int g = 0; g < mg->world; g++) mg->records_sent += (g > 0 ? cap[g] + 1 : 0) + (g < mg->world - 1 ? cap[g + 1] + 1 : 0);
+    mg->exchanges++;
     for (Slab& s : mg->slabs) {
         HIP_OK(hipSetDevice(s.device));
         HIP_OK(hipEventRecord(s.packed, s.compute));
@@ -173,8 +221,8 @@ int exchange(SphMg* mg) {
             Slab& s = mg->slabs[g];
             HIP_OK(hipSetDevice(s.device));
             for (int o = std::max(g - 1, 0); o <= std::min(g + 1, mg->world - 1); o++) HIP_OK(hipStreamWaitEvent(s.comm_stream, mg->slabs[o].packed, 0));
-            if (g > 0) HIP_OK(hipMemcpyAsync(mg->slabs[g - 1].recv_r, s.send_l, bytes, hipMemcpyDefault, s.comm_stream));
-            if (g < mg->world - 1) HIP_OK(hipMemcpyAsync(mg->slabs[g + 1].recv_l, s.send_r, bytes, hipMemcpyDefault, s.comm_stream));
+            if (g > 0) HIP_OK(hipMemcpyAsync(mg->slabs[g - 1].recv_r, s.send_l, msg_bytes(cap[g]), hipMemcpyDefault, s.comm_stream));
+            if (g < mg->world - 1) HIP_OK(hipMemcpyAsync(mg->slabs[g + 1].recv_l, s.send_r, msg_bytes(cap[g + 1]), hipMemcpyDefault, s.comm_stream));
             HIP_OK(hipEventRecord(s.received, s.comm_stream));
         }
         return SPHHIP_OK;
@@ -187,12 +235,12 @@ int exchange(SphMg* mg) {
     for (int g = 0; g < mg->world; g++) {
         Slab& s = mg->slabs[g];
         if (g > 0) {
-            NCCL_OK(ncclSend(s.send_l, bytes, ncclInt8, g - 1, s.comm, s.comm_stream));
-            NCCL_OK(ncclRecv(s.recv_l, bytes, ncclInt8, g - 1, s.comm, s.comm_stream));
+            NCCL_OK(ncclSend(s.send_l, msg_bytes(cap[g]), ncclInt8, g - 1, s.comm, s.comm_stream));
+            NCCL_OK(ncclRecv(s.recv_l, msg_bytes(cap[g]), ncclInt8, g - 1, s.comm, s.comm_stream));
         }
         if (g < mg->world - 1) {
-            NCCL_OK(ncclSend(s.send_r, bytes, ncclInt8, g + 1, s.comm, s.comm_stream));
-            NCCL_OK(ncclRecv(s.recv_r, bytes, ncclInt8, g + 1, s.comm, s.comm_stream));
+            NCCL_OK(ncclSend(s.send_r, msg_bytes(cap[g + 1]), ncclInt8, g + 1, s.comm, s.comm_stream));
+            NCCL_OK(ncclRecv(s.recv_r, msg_bytes(cap[g + 1]), ncclInt8, g + 1, s.comm, s.comm_stream));
         }
     }
     NCCL_OK(ncclGroupEnd());
@@ -203,25 +251,48 @@ int exchange(SphMg* mg) {
     return SPHHIP_OK;
 }
 
-int append_received(SphMg* mg) {
+// The first exchange of every neighbour pair, header records only (the message buffers are zero: "0 records"), then a
+// wait for all of it.
+int warm_up_transport(SphMg* mg) {
+    NCCL_OK(ncclGroupStart());
+    for (int g = 0; g < mg->world; g++) {
+        Slab& s = mg->slabs[g];
+        if (g > 0) {
+            NCCL_OK(ncclSend(s.send_l, sizeof(HaloRec), ncclInt8, g - 1, s.comm, s.comm_stream));
+            NCCL_OK(ncclRecv(s.recv_l, sizeof(HaloRec), ncclInt8, g - 1, s.comm, s.comm_stream));
+        }
+        if (g < mg->world - 1) {
+            NCCL_OK(ncclSend(s.send_r, sizeof(HaloRec), ncclInt8, g + 1, s.comm, s.comm_stream));
+            NCCL_OK(ncclRecv(s.recv_r, sizeof(HaloRec), ncclInt8, g + 1, s.comm, s.comm_stream));
+        }
+    }
+    NCCL_OK(ncclGroupEnd());
+    for (Slab& s : mg->slabs) {
+        HIP_OK(hipSetDevice(s.device));
+        HIP_OK(hipStreamSynchronize(s.comm_stream));
+    }
+    return SPHHIP_OK;
+}
+
+int append_received(SphMg* mg, const std::vector<int>& cap) {
     HostTimer ht(mg, 2);
     for (int g = 0; g < mg->world; g++) {
         Slab& s = mg->slabs[g];
         HIP_OK(hipSetDevice(s.device));
         // own transfers done (the send buffers are free again) and, for the copy transport, the neighbours' pushes too
         for (int o = std::max(g - 1, 0); o <= std::min(g + 1, mg->world - 1); o++) HIP_OK(hipStreamWaitEvent(s.compute, mg->slabs[o].received, 0));
-        SPH_OK(sphhip_append_messages(s.ctx, g > 0 ? s.recv_l : nullptr, g < mg->world - 1 ? s.recv_r : nullptr, mg->cap));
+        SPH_OK(sphhip_append_messages(s.ctx, g > 0 ? s.recv_l : nullptr, cap[g], g < mg->world - 1 ? s.recv_r : nullptr, cap[g + 1]));
     }
     return SPHHIP_OK;
 }
 
-int pack_all(SphMg* mg) {
+int pack_all(SphMg* mg, const std::vector<int>& cap) {
     HostTimer ht(mg, 0);
     for (int g = 0; g < mg->world; g++) {
         Slab& s = mg->slabs[g];
         const bool has_l = g > 0, has_r = g < mg->world - 1;
         SPH_OK(sphhip_pack_halo_async(s.ctx, has_l ? s.c0 + HALO : -1, has_r ? s.c1 - HALO : BIG, has_l ? s.send_l : nullptr,
-                                      has_r ? s.send_r : nullptr, mg->cap));
+                                      has_l ? cap[g] : 0, has_r ? s.send_r : nullptr, has_r ? cap[g + 1] : 0));
     }
     return SPHHIP_OK;
 }
@@ -240,7 +311,9 @@ int run_steps(SphMg* mg, float mx, float my, float strength, int k) {
     for (int i = 0; i < k; i++) {
         if (!mg->have_halo) {
             int rc;
-            if ((rc = pack_all(mg)) || (rc = exchange(mg)) || (rc = append_received(mg))) return rc;
+            const std::vector<int>& cap = i == 0 ? mg->cap_first : mg->cap;
+            if ((rc = pack_all(mg, cap)) || (rc = exchange_all(mg, cap)) || (rc = append_received(mg, cap))) return rc;
+            mg->cap_first = mg->cap;  // (the hand-over after a rebalance is done)
         }
         mg->have_halo = false;
         mg->timed_steps++;
@@ -256,12 +329,12 @@ int run_steps(SphMg* mg, float mx, float my, float strength, int k) {
                                          g < mg->world - 1 ? SPHHIP_PACK_REACH : 0));
         }
         int rc;
-        if ((rc = pack_all(mg)) || (rc = exchange(mg))) return rc;
+        if ((rc = pack_all(mg, mg->cap)) || (rc = exchange_all(mg, mg->cap))) return rc;
         {
             HostTimer ht(mg, 4);
             for (Slab& s : mg->slabs) SPH_OK(sphhip_step_finish(s.ctx));
         }
-        if ((rc = append_received(mg))) return rc;
+        if ((rc = append_received(mg, mg->cap))) return rc;
         mg->have_halo = true;
     }
     return SPHHIP_OK;
@@ -305,36 +378,36 @@ class HostBarrier {
     bool broken_ = false;
 };
 
-int slab_pack(SphMg* mg, int g) {
+int slab_pack(SphMg* mg, int g, const std::vector<int>& cap) {
     Slab& s = mg->slabs[g];
     const bool has_l = g > 0, has_r = g < mg->world - 1;
     SPH_OK(sphhip_pack_halo_async(s.ctx, has_l ? s.c0 + HALO : -1, has_r ? s.c1 - HALO : BIG, has_l ? s.send_l : nullptr,
-                                  has_r ? s.send_r : nullptr, mg->cap));
+                                  has_l ? cap[g] : 0, has_r ? s.send_r : nullptr, has_r ? cap[g + 1] : 0));
     return SPHHIP_OK;
 }
 
 // Starts slab g's transfers on its communication stream, ordered behind the pack just enqueued.
-int slab_send(SphMg* mg, int g, HostBarrier& bar) {
+int slab_send(SphMg* mg, int g, HostBarrier& bar, const std::vector<int>& cap) {
     Slab& s = mg->slabs[g];
-    const size_t bytes = sizeof(HaloRec) * ((size_t)mg->cap + 1);
+    const size_t bytes_l = msg_bytes(cap[g]), bytes_r = msg_bytes(cap[g + 1]);
     HIP_OK(hipEventRecord(s.packed, s.compute));
     if (mg->copy_transport) {
         if (!bar.wait()) return fail(SPHHIP_ESTATE, "another slab failed");  // the neighbours' `packed` are recorded
         for (int o = std::max(g - 1, 0); o <= std::min(g + 1, mg->world - 1); o++) HIP_OK(hipStreamWaitEvent(s.comm_stream, mg->slabs[o].packed, 0));
-        if (g > 0) HIP_OK(hipMemcpyAsync(mg->slabs[g - 1].recv_r, s.send_l, bytes, hipMemcpyDefault, s.comm_stream));
-        if (g < mg->world - 1) HIP_OK(hipMemcpyAsync(mg->slabs[g + 1].recv_l, s.send_r, bytes, hipMemcpyDefault, s.comm_stream));
+        if (g > 0) HIP_OK(hipMemcpyAsync(mg->slabs[g - 1].recv_r, s.send_l, bytes_l, hipMemcpyDefault, s.comm_stream));
+        if (g < mg->world - 1) HIP_OK(hipMemcpyAsync(mg->slabs[g + 1].recv_l, s.send_r, bytes_r, hipMemcpyDefault, s.comm_stream));
         HIP_OK(hipEventRecord(s.received, s.comm_stream));
         return SPHHIP_OK;
     }
     HIP_OK(hipStreamWaitEvent(s.comm_stream, s.packed, 0));
     NCCL_OK(ncclGroupStart());
     if (g > 0) {
-        NCCL_OK(ncclSend(s.send_l, bytes, ncclInt8, g - 1, s.comm, s.comm_stream));
-        NCCL_OK(ncclRecv(s.recv_l, bytes, ncclInt8, g - 1, s.comm, s.comm_stream));
+        NCCL_OK(ncclSend(s.send_l, bytes_l, ncclInt8, g - 1, s.comm, s.comm_stream));
+        NCCL_OK(ncclRecv(s.recv_l, bytes_l, ncclInt8, g - 1, s.comm, s.comm_stream));
     }
     if (g < mg->world - 1) {
-        NCCL_OK(ncclSend(s.send_r, bytes, ncclInt8, g + 1, s.comm, s.comm_stream));
-        NCCL_OK(ncclRecv(s.recv_r, bytes, ncclInt8, g + 1, s.comm, s.comm_stream));
+        NCCL_OK(ncclSend(s.send_r, bytes_r, ncclInt8, g + 1, s.comm, s.comm_stream));
+        NCCL_OK(ncclRecv(s.recv_r, bytes_r, ncclInt8, g + 1, s.comm, s.comm_stream));
     }
     NCCL_OK(ncclGroupEnd());
     HIP_OK(hipEventRecord(s.received, s.comm_stream));
@@ -342,7 +415,7 @@ int slab_send(SphMg* mg, int g, HostBarrier& bar) {
 }
 
 // Makes slab g's compute stream wait for its messages and appends them.
-int slab_receive(SphMg* mg, int g, HostBarrier& bar) {
+int slab_receive(SphMg* mg, int g, HostBarrier& bar, const std::vector<int>& cap) {
     Slab& s = mg->slabs[g];
     if (mg->copy_transport) {
         if (!bar.wait()) return fail(SPHHIP_ESTATE, "another slab failed");  // the neighbours' `received` are recorded
@@ -350,7 +423,7 @@ int slab_receive(SphMg* mg, int g, HostBarrier& bar) {
     } else {
         HIP_OK(hipStreamWaitEvent(s.compute, s.received, 0));
     }
-    SPH_OK(sphhip_append_messages(s.ctx, g > 0 ? s.recv_l : nullptr, g < mg->world - 1 ? s.recv_r : nullptr, mg->cap));
+    SPH_OK(sphhip_append_messages(s.ctx, g > 0 ? s.recv_l : nullptr, cap[g], g < mg->world - 1 ? s.recv_r : nullptr, cap[g + 1]));
     return SPHHIP_OK;
 }
 
@@ -372,11 +445,14 @@ int slab_steps(SphMg* mg, int g, HostBarrier& bar, float mx, float my, float str
     int rc;
     for (int i = 0; i < k; i++) {
         if (!have_halo) {
-            if ((rc = slab_pack(mg, g))) return rc;
+            // (the first exchange of a run: after a rebalance it hands whole columns over and has a size of its own;
+            // cap_first is reset by run_steps_threaded once every thread is done with it)
+            const std::vector<int>& cap = i == 0 ? mg->cap_first : mg->cap;
+            if ((rc = slab_pack(mg, g, cap))) return rc;
             lap.mark(0);
-            if ((rc = slab_send(mg, g, bar))) return rc;
+            if ((rc = slab_send(mg, g, bar, cap))) return rc;
             lap.mark(1);
-            if ((rc = slab_receive(mg, g, bar))) return rc;
+            if ((rc = slab_receive(mg, g, bar, cap))) return rc;
             lap.mark(2);
         }
         have_halo = false;
@@ -388,13 +464,13 @@ int slab_steps(SphMg* mg, int g, HostBarrier& bar, float mx, float my, float str
         }
         SPH_OK(sphhip_step_begin(s.ctx, mx, my, strength, g > 0 ? SPHHIP_PACK_REACH : 0, g < mg->world - 1 ? SPHHIP_PACK_REACH : 0));
         lap.mark(3);
-        if ((rc = slab_pack(mg, g))) return rc;
+        if ((rc = slab_pack(mg, g, mg->cap))) return rc;
         lap.mark(0);
-        if ((rc = slab_send(mg, g, bar))) return rc;  // travels while the interior columns are computed
+        if ((rc = slab_send(mg, g, bar, mg->cap))) return rc;  // travels while the interior columns are computed
         lap.mark(1);
         SPH_OK(sphhip_step_finish(s.ctx));
         lap.mark(4);
-        if ((rc = slab_receive(mg, g, bar))) return rc;
+        if ((rc = slab_receive(mg, g, bar, mg->cap))) return rc;
         lap.mark(2);
         have_halo = true;
     }
@@ -417,6 +493,28 @@ int run_steps_threaded(SphMg* mg, float mx, float my, float strength, int k) {
         });
     for (std::thread& t : team) t.join();
     mg->have_halo = false;  // the last step of a run is never split
+    {
+        long long per_exchange = 0;
+        for (int g = 0; g < mg->world; g++) per_exchange += (g > 0 ? mg->cap[g] + 1 : 0) + (g < mg->world - 1 ? mg->cap[g + 1] + 1 : 0);
+        long long first = 0;
+        for (int g = 0; g < mg->world; g++) first += (g > 0 ? mg->cap_first[g] + 1 : 0) + (g < mg->world - 1 ? mg->cap_first[g + 1] + 1 : 0);
+        mg->records_sent += first + per_exchange * (k - 1);
+        mg->exchanges += k;
+    }
+    mg->cap_first = mg->cap;  // (the hand-over after a rebalance is done)
+    bool failed = false;
+    for (int g = 0; g < mg->world; g++) failed = failed || rcs[g] != 0;
+    if (failed && !mg->copy_transport) {
+        // A slab that failed returned before its ncclGroupEnd, its neighbours' send / recv kernels would wait for it
+        // for ever (and with them sphmg_synchronize / sphmg_destroy): abort the communicators, which makes those
+        // kernels exit, and refuse further work on this object.
+        for (Slab& s : mg->slabs)
+            if (s.comm) {
+                (void)ncclCommAbort(s.comm);
+                s.comm = nullptr;
+            }
+        mg->broken = true;
+    }
     for (int g = 0; g < mg->world; g++)
         if (rcs[g] && msgs[g] != "another slab failed") return fail(rcs[g], "slab " + std::to_string(g) + ": " + msgs[g]);
     for (int g = 0; g < mg->world; g++)
@@ -439,7 +537,6 @@ void destroy(SphMg* mg) {
         if (s.packed) (void)hipEventDestroy(s.packed);
         if (s.received) (void)hipEventDestroy(s.received);
         if (s.comm_stream) (void)hipStreamDestroy(s.comm_stream);
-        if (s.compute) (void)hipStreamDestroy(s.compute);
     }
     delete mg;
 }
@@ -505,8 +602,13 @@ extern "C" int sphmg_create(const SphParams* p, const void* aos28, int n, int n_
         for (int k = bounds[g]; k < bounds[g + 1]; k++) c += hist[k];
         per = std::max(per, c);
     }
-    const int cap = halo_capacity(hist);
-    // the balanced share with room for imbalance between two rebalances, plus ghosts and in-flight messages
+    if (const char* e = std::getenv("SPHMG_HALO_MARGIN"))
+        if (std::atof(e) >= 1.0) mg->halo_margin = std::atof(e);
+    mg->cap = steady_caps(hist, bounds, mg->halo_margin, floor_records());
+    mg->cap_first = mg->cap;
+    const int cap = std::max(*std::max_element(mg->cap.begin(), mg->cap.end()), HALO_FLOOR);
+    // the balanced share with room for imbalance between two rebalances, plus ghosts (two halos: last step's stale
+    // copies and the fresh ones) with room to grow
     const long long n_max = n_gpus == 1 ? std::max(n, 1) : per + per / 2 + 8ll * cap + 1024;
     auto bail = [&](int rc) {
         destroy(mg);
@@ -516,12 +618,13 @@ extern "C" int sphmg_create(const SphParams* p, const void* aos28, int n, int n_
         Slab& s = mg->slabs[g];
         if (hipSetDevice(s.device) != hipSuccess) return bail(fail(SPHHIP_EHIP, "hipSetDevice failed"));
         if (int rc = sphhip_create(p, (int)std::min<long long>(n_max, 1 << 30), s.device, &s.ctx)) return bail(fail(rc, sphhip_last_error()));
-        if (hipStreamCreateWithFlags(&s.compute, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking) != hipSuccess ||
+        if (hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&s.packed, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.received, hipEventDisableTiming) != hipSuccess)
             return bail(fail(SPHHIP_EHIP, "stream / event creation failed"));
-        if (int rc = sphhip_set_stream(s.ctx, s.compute)) return bail(fail(rc, sphhip_last_error()));
+        void* own = nullptr;
+        if (int rc = sphhip_get_stream(s.ctx, &own)) return bail(fail(rc, sphhip_last_error()));
+        s.compute = (hipStream_t)own;
     }
     if (int rc = set_bounds(mg, bounds)) return bail(rc);
     if (n_gpus > 1) {
@@ -541,6 +644,11 @@ extern "C" int sphmg_create(const SphParams* p, const void* aos28, int n, int n_
         ncclResult_t r = ncclCommInitAll(comms.data(), n_gpus, devs.data());
         if (r != ncclSuccess) return bail(fail(SPHHIP_EHIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r)));
         for (int g = 0; g < n_gpus; g++) mg->slabs[g].comm = comms[g];
+        // One header-sized exchange with every neighbour now, from this one thread: RCCL sets its peer connections up
+        // inside the first ncclGroupEnd that uses them, blocking the host -- that must not happen inside the per-slab
+        // enqueue threads (a thread that fails before its group call would leave its neighbours blocked there), and a
+        // transport that does not work is reported here instead of hanging a run.
+        if (int rc = warm_up_transport(mg)) return bail(rc);
     }
     // every slab gets its own particles as 20-byte records {x, y, vx, vy, id | valid}
     for (int g = 0; g < n_gpus; g++) {
@@ -572,23 +680,48 @@ extern "C" int sphmg_create(const SphParams* p, const void* aos28, int n, int n_
     return SPHHIP_OK;
 }
 
+#define NOT_BROKEN(mg) \
+    if ((mg)->broken) return fail(SPHHIP_ESTATE, "a slab failed during an RCCL run: the communicators were aborted; destroy this object")
+
 extern "C" int sphmg_rebalance(SphMg* mg) {
     if (!mg) return fail(SPHHIP_EINVAL, "null");
+    NOT_BROKEN(mg);
     std::vector<long long> hist;
-    if (int rc = histogram(mg, hist)) return rc;
+    if (int rc = histogram(mg, hist)) return rc;  // (synchronises every slab)
     const std::vector<int> prev = mg->bounds;
     if (int rc = set_bounds(mg, balanced_bounds(hist, mg->world, &prev))) return rc;
-    const int want = halo_capacity(hist);
-    if (mg->world > 1 && want > mg->cap) {
-        for (Slab& s : mg->slabs) SPH_OK(sphhip_synchronize(s.ctx));
-        if (int rc = alloc_messages(mg, want)) return rc;
+    if (mg->world > 1) {
+        // message sizes of the new boundaries; the next exchange hands the columns between old and new over
+        mg->cap = steady_caps(hist, mg->bounds, mg->halo_margin, floor_records());
+        mg->cap_first = handover_caps(hist, prev, mg->bounds, mg->cap);
+        const int want = std::max(*std::max_element(mg->cap.begin(), mg->cap.end()), *std::max_element(mg->cap_first.begin(), mg->cap_first.end()));
+        if (want > mg->cap_alloc) {
+            for (Slab& s : mg->slabs) {
+                HIP_OK(hipSetDevice(s.device));
+                HIP_OK(hipStreamSynchronize(s.comm_stream));
+                SPH_OK(sphhip_synchronize(s.ctx));
+            }
+            if (int rc = alloc_messages(mg, want)) return rc;
+        }
     }
     mg->rebalances++;
     return SPHHIP_OK;
 }
 
+extern "C" int sphmg_halo_stats(SphMg* mg, long long* exchanges, double* bytes_per_exchange_per_slab, int* max_message_records) {
+    if (!mg) return fail(SPHHIP_EINVAL, "null");
+    if (exchanges) *exchanges = mg->exchanges;
+    if (bytes_per_exchange_per_slab)
+        *bytes_per_exchange_per_slab = mg->exchanges ? (double)sizeof(HaloRec) * (double)mg->records_sent / ((double)mg->exchanges * mg->world) : 0.0;
+    if (max_message_records) *max_message_records = mg->cap.empty() ? 0 : *std::max_element(mg->cap.begin(), mg->cap.end());
+    return SPHHIP_OK;
+}
+
+extern "C" const char* sphmg_transport(SphMg* mg) { return !mg || mg->world < 2 ? "none" : mg->copy_transport ? "copy" : "rccl"; }
+
 extern "C" int sphmg_step(SphMg* mg, float mx, float my, float strength, int nsteps, int rebalance_every) {
     if (!mg || nsteps < 0) return fail(SPHHIP_EINVAL, "sphmg_step: bad argument");
+    NOT_BROKEN(mg);
     int done = 0;
     while (done < nsteps) {
         const int k = rebalance_every > 0 ? std::min(rebalance_every, nsteps - done) : nsteps - done;
@@ -602,6 +735,7 @@ extern "C" int sphmg_step(SphMg* mg, float mx, float my, float strength, int nst
 
 extern "C" int sphmg_synchronize(SphMg* mg) {
     if (!mg) return fail(SPHHIP_EINVAL, "null");
+    NOT_BROKEN(mg);
     for (Slab& s : mg->slabs) {
         HIP_OK(hipSetDevice(s.device));
         HIP_OK(hipStreamSynchronize(s.comm_stream));

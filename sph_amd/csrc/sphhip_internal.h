@@ -200,6 +200,8 @@ int sph_pack_aos(SphCtx* c, int n, uint32_t* d_ids_out);
 // phase timing helpers
 void sph_phase_begin(SphCtx* c, int ph);
 void sph_phase_end(SphCtx* c, int ph);
+void sph_phase_begin(SphCtx* c, int ph, hipStream_t on);  // ... on another stream than the context's (the side stream)
+void sph_phase_end(SphCtx* c, int ph, hipStream_t on);
 
 struct PhaseScope {
     SphCtx* c;

@@ -10,7 +10,7 @@ from .params import SphDerived, SphParams
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPHHIP_LIB") or os.path.join(_HERE, "libsphhip.so")  # override: kernel A/B builds only
 
-PH_NAMES = ["hash", "sort", "cells", "reorder", "density", "force", "integrate"]
+PH_NAMES = ["hash", "sort", "cells", "reorder", "density", "force", "integrate", "force_interior"]
 
 _vp = ctypes.c_void_p
 _ci = ctypes.c_int
@@ -45,9 +45,9 @@ SIGNATURES = {
     "sphhip_get_neighbor_counts": [_vp, _vp, _ci],
     "sphhip_set_owned_columns": [_vp, _ci, _ci],
     "sphhip_pack_halo": [_vp, _ci, _ci, _vp, _ci, _pi, _vp, _ci, _pi],
-    "sphhip_pack_halo_async": [_vp, _ci, _ci, _vp, _vp, _ci],
+    "sphhip_pack_halo_async": [_vp, _ci, _ci, _vp, _ci, _vp, _ci],
     "sphhip_append_message": [_vp, _vp, _ci],
-    "sphhip_append_messages": [_vp, _vp, _vp, _ci],
+    "sphhip_append_messages": [_vp, _vp, _ci, _vp, _ci],
     "sphhip_sync_counts": [_vp, _pi],
     "sphhip_keep_columns": [_vp, _ci, _ci],
     "sphhip_drop_ghosts": [_vp],

@@ -28,6 +28,7 @@ SIGNATURES = {
     "sphmg_rebalance_count": [_vp],
     "sphmg_destroy": [_vp],
     "sphmg_selftest_transport": [_ci, _ci],
+    "sphmg_halo_stats": [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double), _pi],
 }
 
 _mg = None
@@ -48,6 +49,8 @@ def load():
         fn.restype = ctypes.c_int
     mg.sphmg_last_error.restype = ctypes.c_char_p
     mg.sphmg_last_error.argtypes = []
+    mg.sphmg_transport.restype = ctypes.c_char_p
+    mg.sphmg_transport.argtypes = [_vp]
     _mg = mg
     return mg
 
@@ -100,6 +103,16 @@ class MultiGpuSolver:
         b = (_ci * (self.world + 1))()
         _check(self._mg.sphmg_bounds(self._h, b))
         return list(b)
+
+    def halo_stats(self):
+        """-> dict: exchanges so far, average bytes one slab sent per exchange, largest steady-state message (records)."""
+        ex, by, mx = ctypes.c_longlong(), ctypes.c_double(), _ci()
+        _check(self._mg.sphmg_halo_stats(self._h, ctypes.byref(ex), ctypes.byref(by), ctypes.byref(mx)))
+        return {"exchanges": ex.value, "bytes_per_exchange_per_slab": by.value, "max_message_records": mx.value}
+
+    @property
+    def transport(self):
+        return self._mg.sphmg_transport(self._h).decode()
 
     @property
     def rebalances(self):

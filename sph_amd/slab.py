@@ -69,10 +69,43 @@ def balanced_bounds(hist, world, min_width=MIN_SLAB_COLS, prev=None):
     return b
 
 
-def halo_capacity(hist, margin=2.5, floor=4096):
-    """Records a halo message must hold: the particles of SPHHIP_HALO_COLS columns plus migrants, sized from the
-    fullest column of the (global) histogram with a margin for compression between two rebalances."""
-    return int(max(margin * HALO_COLS * float(np.max(hist)), floor))
+HALO_MARGIN = float(os.environ.get("SPH_HALO_MARGIN", "1.25"))  # steady-state message size over the halo's population
+HALO_FLOOR = 1024
+
+
+def steady_caps(hist, bounds, margin=None, floor=None):
+    """Records per message across every inner slab boundary between two rebalances (list indexed by boundary g =
+    1 .. world-1; entries 0 and world are 0).  A message carries the SPHHIP_HALO_COLS columns next to the boundary
+    plus the few migrants of one step; it is sized from the fullest column within reach of the boundary (the halo
+    and two columns more on each side: what a front moving at MAX_VEL can bring there in 100 steps), times `margin`.
+    Sender and receiver compute the same number from the same global histogram -- that is what lets a message
+    travel at a size the host fixes beforehand (no count round trip) while shipping about what is needed, not the
+    2.5 x fullest-column-of-the-domain of the first version."""
+    margin = HALO_MARGIN if margin is None else margin
+    floor = HALO_FLOOR if floor is None else floor
+    hist = np.asarray(hist, np.int64)
+    caps = [0] * len(bounds)
+    for g in range(1, len(bounds) - 1):
+        b = bounds[g]
+        near = hist[max(b - HALO_COLS - 2, 0):b + HALO_COLS + 2]
+        caps[g] = int(max(margin * HALO_COLS * float(near.max() if len(near) else 0), floor))
+    return caps
+
+
+def handover_caps(hist, old, new, steady):
+    """Records per message of the FIRST exchange after the boundaries moved from `old` to `new`: that exchange hands
+    over every column between the old and the new boundary besides the halo.  The histogram was taken at the
+    rebalance itself, so the sum over those columns is what the message will hold (plus 1/16 + 256: migrants that are
+    still with their old owner are counted at their new column)."""
+    hist = np.asarray(hist, np.int64)
+    caps = list(steady)
+    for g in range(1, len(new) - 1):
+        if old[g] == new[g]:
+            continue
+        lo, hi = min(old[g], new[g]) - HALO_COLS, max(old[g], new[g]) + HALO_COLS
+        need = int(hist[max(lo, 0):hi].sum())
+        caps[g] = max(steady[g], need + need // 16 + 256)
+    return caps
 
 
 class HipSlabBackend:
@@ -87,12 +120,16 @@ class HipSlabBackend:
         # run the library on torch's current stream so that RCCL ops and kernels are ordered
         self.solver.follow_torch_stream(torch.cuda.current_stream(self.device))
         self.n_max = int(n_max)
-        self.set_halo_cap(halo_cap)
+        self.cap = 0
+        self.reserve(halo_cap)
 
-    def set_halo_cap(self, halo_cap):
-        """(Re)allocates the four fixed-size message buffers: (cap + 1) 20-byte records each.  Sender and receiver
-        must agree on the size, so the capacity is always derived from data every rank holds (the global column
-        histogram)."""
+    def reserve(self, halo_cap):
+        """Makes the four message buffers hold at least (halo_cap + 1) 20-byte records each (grow only; called at
+        set-up and at a rebalance, never inside a run of steps).  What travels is a prefix of a buffer: the size of
+        every exchange is fixed by the SlabSolver per slab boundary (steady_caps / handover_caps)."""
+        if int(halo_cap) <= self.cap:
+            return
+        torch.cuda.synchronize(self.device)
         self.cap = int(halo_cap)
         mk = lambda: torch.zeros((self.cap + 1, 5), dtype=torch.int32, device=self.device)  # noqa: E731
         self.send_l, self.send_r, self.recv_l, self.recv_r = mk(), mk(), mk(), mk()
@@ -100,19 +137,21 @@ class HipSlabBackend:
     def set_owned(self, lo, hi):
         self.solver.set_owned_columns(lo, hi)
 
-    def pack(self, send_hi_left, send_lo_right, has_left, has_right):
-        """Enqueues the split; returns the two outgoing messages (None where there is no neighbour)."""
-        self.solver.pack_halo_async(send_hi_left, send_lo_right, self.send_l.data_ptr() if has_left else None,
-                                    self.send_r.data_ptr() if has_right else None, self.cap)
-        return (self.send_l if has_left else None), (self.send_r if has_right else None)
+    def pack(self, send_hi_left, send_lo_right, cap_left, cap_right):
+        """Enqueues the split; returns the two outgoing messages, header + cap records each (None where there is
+        no neighbour: cap 0)."""
+        assert max(cap_left, cap_right) <= self.cap
+        self.solver.pack_halo_async(send_hi_left, send_lo_right, self.send_l.data_ptr() if cap_left else None, cap_left,
+                                    self.send_r.data_ptr() if cap_right else None, cap_right)
+        return (self.send_l[:cap_left + 1] if cap_left else None), (self.send_r[:cap_right + 1] if cap_right else None)
 
-    def recv_buffers(self):
-        return self.recv_l, self.recv_r
+    def recv_buffers(self, cap_left, cap_right):
+        return (self.recv_l[:cap_left + 1] if cap_left else None), (self.recv_r[:cap_right + 1] if cap_right else None)
 
-    def finish(self, has_left, has_right):
+    def finish(self, cap_left, cap_right):
         """Appends what was received; counts stay on the device (no host synchronisation)."""
-        self.solver.append_messages(self.recv_l.data_ptr() if has_left else None,
-                                    self.recv_r.data_ptr() if has_right else None, self.cap)
+        self.solver.append_messages(self.recv_l.data_ptr() if cap_left else None, cap_left,
+                                    self.recv_r.data_ptr() if cap_right else None, cap_right)
 
     def check(self):
         """Synchronises and raises if a halo buffer or the particle capacity overflowed."""
@@ -152,7 +191,7 @@ class HipSlabBackend:
 class SlabSolver:
     """x-slab decomposition of one scene over the ranks of a process group."""
 
-    def __init__(self, backend, params, bounds, group=None):
+    def __init__(self, backend, params, bounds, group=None, hist=None):
         self.backend = backend
         self.params = params
         self.group = group
@@ -167,7 +206,14 @@ class SlabSolver:
         self.last_hist = None
         self.last_spread = None
         self.rebalances = 0
+        self.records_sent = 0  # records' worth of bytes this rank has sent (headers included), and in how many exchanges
+        self.exchanges = 0
         self.set_bounds(bounds)
+        if hist is not None:
+            self.last_hist = np.asarray(hist, np.int64)
+            self.set_caps(steady_caps(hist, self.bounds))
+        else:  # (tests that drive a backend without a histogram: one size for everything)
+            self.set_caps([0] + [getattr(backend, "CAP", HALO_FLOOR)] * (self.world - 1) + [0])
 
     # -- partition ----------------------------------------------------------------------------
     def set_bounds(self, bounds):
@@ -179,11 +225,26 @@ class SlabSolver:
         self.c0, self.c1 = bounds[self.rank], bounds[self.rank + 1]
         self.backend.set_owned(self.c0, self.c1)
 
+    def set_caps(self, steady, first=None):
+        """Message sizes (records) per slab boundary: `steady` between two rebalances, `first` for the next exchange
+        only (the hand-over after the boundaries moved)."""
+        self.caps = list(steady)
+        self.caps_first = list(first) if first is not None else None
+        reserve = getattr(self.backend, "reserve", None)
+        if reserve is not None:
+            reserve(max(list(steady) + (list(first) if first is not None else [])))
+        self._ops_cache = {}
+
+    def _caps_now(self):
+        """(cap_left, cap_right) of the coming exchange; 0 where there is no neighbour."""
+        c = self.caps_first if self.caps_first is not None else self.caps
+        return (c[self.rank] if self.rank > 0 else 0), (c[self.rank + 1] if self.rank < self.world - 1 else 0)
+
     def rebalance(self):
         """Count-balanced boundaries from the global per-column histogram (one small all-reduce).  The same histogram
-        re-sizes the halo messages: every rank sees the same numbers, so sender and receiver stay in agreement, and
-        a column that has filled up since the last rebalance (the collapsing dam) cannot overflow them -- the
-        capacity only ever grows.  Returns the new boundaries."""
+        re-sizes the halo messages, per boundary: every rank sees the same numbers, so sender and receiver stay in
+        agreement.  The first exchange after the move hands over whole columns and gets a message sized for exactly
+        that (handover_caps); from then on the steady size applies.  Returns the new boundaries."""
         self.backend.drop_ghosts()
         h = torch.from_numpy(self.backend.column_histogram().astype(np.int64))
         dev = getattr(self.backend, "device", torch.device("cpu"))
@@ -192,14 +253,11 @@ class SlabSolver:
         hist = h.cpu().numpy()
         self.last_hist = hist
         before = self.owned_counts()
-        self.set_bounds(balanced_bounds(hist, self.world, prev=self.bounds))
+        old = list(self.bounds)
+        self.set_bounds(balanced_bounds(hist, self.world, prev=old))
         self.last_spread = (before, self.owned_counts())  # particles per rank under the old / the new boundaries
-        set_cap = getattr(self.backend, "set_halo_cap", None)
-        if set_cap is not None:
-            want = halo_capacity(hist)
-            if want > self.backend.cap:
-                set_cap(want)
-                self._ops_cache = {}
+        steady = steady_caps(hist, self.bounds)
+        self.set_caps(steady, handover_caps(hist, old, self.bounds, steady))
         self.rebalances += 1
         return self.bounds
 
@@ -224,7 +282,7 @@ class SlabSolver:
             recv_l = torch.empty(recv_l.shape, dtype=recv_l.dtype) if left is not None else None
             recv_r = torch.empty(recv_r.shape, dtype=recv_r.dtype) if right is not None else None
         # (the backend's message buffers are fixed: the op list is built once and reused every step)
-        key = tuple(t.data_ptr() if t is not None else 0 for t in (left, right, recv_l, recv_r))
+        key = tuple((t.data_ptr(), t.shape[0]) if t is not None else 0 for t in (left, right, recv_l, recv_r))
         ops = self._ops_cache.get(key) if not stage else None
         if ops is None:
             ops = []
@@ -281,20 +339,35 @@ class SlabSolver:
         split = self.overlap and hasattr(self.backend, "step_begin") and (has_l or has_r)
         for i in range(nsteps):
             if i == 0 or not split:
-                left, right = self.backend.pack(send_hi_left, send_lo_right, has_l, has_r)
-                recv_l, recv_r = self.backend.recv_buffers()
+                cl, cr = self._caps_now()
+                left, right = self.backend.pack(send_hi_left, send_lo_right, cl, cr)
+                recv_l, recv_r = self.backend.recv_buffers(cl, cr)
                 self._exchange(left, right, recv_l, recv_r)
-                self.backend.finish(has_l, has_r)
+                self.backend.finish(cl, cr)
+                self._sent(cl, cr)
             if not split or i == nsteps - 1:
                 self.backend.step(mouse, strength)
                 continue
             self.backend.step_begin(mouse, strength, has_l, has_r)
-            left, right = self.backend.pack(send_hi_left, send_lo_right, has_l, has_r)
-            recv_l, recv_r = self.backend.recv_buffers()
+            cl, cr = self._caps_now()
+            left, right = self.backend.pack(send_hi_left, send_lo_right, cl, cr)
+            recv_l, recv_r = self.backend.recv_buffers(cl, cr)
             handle = self._exchange_start(left, right, recv_l, recv_r)
             self.backend.step_finish()
             self._exchange_wait(handle)
-            self.backend.finish(has_l, has_r)
+            self.backend.finish(cl, cr)
+            self._sent(cl, cr)
+
+    def _sent(self, cl, cr):
+        self.records_sent += (cl + 1 if cl else 0) + (cr + 1 if cr else 0)
+        self.exchanges += 1
+        if self.caps_first is not None:  # the hand-over after a rebalance is done: back to the steady size
+            self.caps_first = None
+            self._ops_cache = {}
+
+    def bytes_per_exchange(self):
+        """Average bytes this rank has sent per exchange (both directions, headers included)."""
+        return 20.0 * self.records_sent / max(self.exchanges, 1)
 
     # -- state --------------------------------------------------------------------------------
     def download_local(self):
@@ -355,12 +428,12 @@ def make_hip_slab(params, particles_or_fn, device, group=None, hist=None):
         hist = np.bincount(col, minlength=drv.nx)
     bounds = balanced_bounds(hist, world)
     per = int(np.max([np.sum(hist[bounds[g]:bounds[g + 1]]) for g in range(world)]))
-    halo_cap = halo_capacity(hist)  # fixed message size: 2.5x the fullest halo; re-sized at every rebalance
-    # particle capacity: the balanced share with room for imbalance between two rebalances, plus ghosts and
-    # in-flight messages at a grown halo capacity
+    halo_cap = max(steady_caps(hist, bounds) + [HALO_FLOOR])
+    # particle capacity: the balanced share with room for imbalance between two rebalances, plus ghosts (two halos,
+    # last step's stale copies and the fresh ones) with room to grow
     n_max = int(per * 1.5) + 8 * halo_cap + 1024
     backend = HipSlabBackend(params, n_max, device, halo_cap)
-    slab = SlabSolver(backend, params, bounds, group)
+    slab = SlabSolver(backend, params, bounds, group, hist=hist)
     if callable(particles_or_fn):
         a, ids = particles_or_fn(slab.c0, slab.c1, drv)
         backend.append_host(records_from_particles(a, ids))

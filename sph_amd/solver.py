@@ -185,16 +185,16 @@ class Solver:
                                            ctypes.byref(nr)))
         return nl.value, nr.value
 
-    def pack_halo_async(self, send_hi_left, send_lo_right, d_msg_left, d_msg_right, cap):
-        _lib.check(self.L.sphhip_pack_halo_async(self.h, int(send_hi_left), int(send_lo_right),
-                                                 ctypes.c_void_p(d_msg_left), ctypes.c_void_p(d_msg_right), int(cap)))
+    def pack_halo_async(self, send_hi_left, send_lo_right, d_msg_left, cap_left, d_msg_right, cap_right):
+        _lib.check(self.L.sphhip_pack_halo_async(self.h, int(send_hi_left), int(send_lo_right), ctypes.c_void_p(d_msg_left),
+                                                 int(cap_left), ctypes.c_void_p(d_msg_right), int(cap_right)))
 
     def append_message(self, d_msg, cap):
         _lib.check(self.L.sphhip_append_message(self.h, ctypes.c_void_p(d_msg), int(cap)))
 
-    def append_messages(self, d_msg_a, d_msg_b, cap):
+    def append_messages(self, d_msg_a, cap_a, d_msg_b, cap_b):
         """Both neighbours' messages in one launch (a first, b behind it); either may be None."""
-        _lib.check(self.L.sphhip_append_messages(self.h, ctypes.c_void_p(d_msg_a), ctypes.c_void_p(d_msg_b), int(cap)))
+        _lib.check(self.L.sphhip_append_messages(self.h, ctypes.c_void_p(d_msg_a), int(cap_a), ctypes.c_void_p(d_msg_b), int(cap_b)))
 
     def sync_counts(self):
         v = ctypes.c_int()

@@ -23,24 +23,26 @@ class FakeSlabBackend:
         self.device = torch.device("cpu")
         self.lo, self.hi = 0, self.drv.nx
 
-    CAP = 4096
+    CAP = 4096  # message size when the SlabSolver was given no histogram to size them from
 
-    def recv_buffers(self):
-        self.recv_l = torch.zeros((self.CAP + 1, 5), dtype=torch.int32)
-        self.recv_r = torch.zeros((self.CAP + 1, 5), dtype=torch.int32)
+    def recv_buffers(self, cap_left, cap_right):
+        self.recv_l = torch.zeros((cap_left + 1, 5), dtype=torch.int32) if cap_left else None
+        self.recv_r = torch.zeros((cap_right + 1, 5), dtype=torch.int32) if cap_right else None
         return self.recv_l, self.recv_r
 
-    def _message(self, rec):
-        assert rec.shape[0] <= self.CAP
-        m = torch.zeros((self.CAP + 1, 5), dtype=torch.int32)
+    def _message(self, rec, cap):
+        # the library flags an overflow (sticky error, records dropped); here it fails the test at once
+        assert rec.shape[0] <= cap, "halo message overflow: %d records, capacity %d" % (rec.shape[0], cap)
+        self.max_fill = max(getattr(self, "max_fill", 0.0), rec.shape[0] / cap)
+        m = torch.zeros((cap + 1, 5), dtype=torch.int32)
         m[0, 0] = rec.shape[0]
         m[1:1 + rec.shape[0]] = rec
         return m
 
-    def finish(self, has_left, has_right):
-        if has_left:
+    def finish(self, cap_left, cap_right):
+        if cap_left:
             self.append(self.recv_l[1:1 + int(self.recv_l[0, 0])])
-        if has_right:
+        if cap_right:
             self.append(self.recv_r[1:1 + int(self.recv_r[0, 0])])
 
     def set_owned(self, lo, hi):
@@ -58,11 +60,11 @@ class FakeSlabBackend:
             self.a, self.ids = self.a[self.owned_mask], self.ids[self.owned_mask]
             self.owned_mask = None
 
-    def pack(self, send_hi_left, send_lo_right, has_left, has_right):
+    def pack(self, send_hi_left, send_lo_right, cap_left, cap_right):
         self.drop_ghosts()
         col = grid_column(self.a["pos"][:, 0], self.params, self.drv)
-        left = self._message(self._records(col < send_hi_left)) if has_left else None
-        right = self._message(self._records(col >= send_lo_right)) if has_right else None
+        left = self._message(self._records(col < send_hi_left), cap_left) if cap_left else None
+        right = self._message(self._records(col >= send_lo_right), cap_right) if cap_right else None
         keep = (col >= self.lo - HALO_COLS) & (col < self.hi + HALO_COLS)  # fresh migrants stay as ghosts
         self.a, self.ids = self.a[keep], self.ids[keep]
         return left, right

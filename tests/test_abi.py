@@ -110,10 +110,11 @@ def test_mg_library_exports_every_declared_symbol():
     src = open(os.path.join(ROOT, "include", "sph_mg.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     syms = sorted(set(re.findall(r"\b(sphmg_[a-z_]+)\s*\(", src)))
-    assert len(syms) == 11
+    assert len(syms) == 13
     for s in syms:
         assert hasattr(M, s), "libsph_mg.so does not export %s" % s
-    assert set(syms) - {"sphmg_last_error"} == set(mg.SIGNATURES)
+    assert set(syms) - {"sphmg_last_error", "sphmg_transport"} == set(mg.SIGNATURES)
+    assert M.sphmg_transport(None) == b"none"
     # argument validation needs no device
     assert M.sphmg_step(None, 0.0, 0.0, 0.0, 1, 0) != 0 and b"bad argument" in M.sphmg_last_error()
     assert M.sphmg_rebalance_count(None) == 0

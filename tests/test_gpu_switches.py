@@ -99,12 +99,12 @@ def test_pack_between_the_halves_of_a_step(monkeypatch):
         # edge widths below SPHHIP_PACK_REACH on a side with a message
         s.stepBegin(edge_left=1, edge_right=3)
         with pytest.raises(SphHipError, match="-3"):
-            s.pack_halo_async(lo + 2, hi - 2, msg.data_ptr(), msg.data_ptr(), cap)
+            s.pack_halo_async(lo + 2, hi - 2, msg.data_ptr(), cap, msg.data_ptr(), cap)
         s.stepFinish()
         # send range wider than the halo: the compacting split may not run mid-step
         s.stepBegin(edge_left=3, edge_right=3)
         with pytest.raises(SphHipError, match="-3"):
-            s.pack_halo_async(lo + 5, hi - 2, msg.data_ptr(), None, cap)
+            s.pack_halo_async(lo + 5, hi - 2, msg.data_ptr(), cap, None, 0)
         s.stepFinish()
         s.synchronize()
     monkeypatch.setenv("SPHHIP_LAZY_PACK", "0")
@@ -113,7 +113,7 @@ def test_pack_between_the_halves_of_a_step(monkeypatch):
         s.upload(a)
         s.keep_columns(lo - 2, hi + 2)
         s.stepBegin(edge_left=3, edge_right=3)
-        s.pack_halo_async(lo + 2, hi - 2, msg.data_ptr(), None, cap)
+        s.pack_halo_async(lo + 2, hi - 2, msg.data_ptr(), cap, None, 0)
         s.stepFinish()
         s.sync_counts()
 

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 import orc
 from sph_amd import lib as _lib
 from sph_amd import scenes
-from sph_amd.slab import SlabSolver, balanced_bounds, distribute, grid_column
+from sph_amd.slab import SlabSolver, balanced_bounds, distribute, grid_column, handover_caps, steady_caps
 
 
 def _free_port():
@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, scene, nsteps, rebalance_every, out_path, overlap="1"):
+def _worker(rank, world, port, scene, nsteps, rebalance_every, out_path, overlap="1", skew=False):
     os.environ["SPH_SLAB_OVERLAP"] = overlap
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,7 +38,13 @@ def _worker(rank, world, port, scene, nsteps, rebalance_every, out_path, overlap
         params, a = _scene(scene)
         backend = FakeSlabBackend(params)
         hist = np.bincount(grid_column(a["pos"][:, 0], params, backend.drv), minlength=backend.drv.nx)
-        slab = SlabSolver(backend, params, balanced_bounds(hist, world))
+        bounds = balanced_bounds(hist, world)
+        if skew:  # start far from balance: a rebalance moves a boundary by many columns at once
+            import sph_amd.slab as slab_mod
+
+            slab_mod.HALO_FLOOR = 16
+            bounds = [0] + [3 * g for g in range(1, world)] + [backend.drv.nx]
+        slab = SlabSolver(backend, params, bounds, hist=hist)
         distribute(slab, a)
         # several steps per call: between the steps of one call the exchange is overlapped with the step
         # (step_begin / pack / step_finish), the first exchange of a call is not
@@ -52,6 +58,7 @@ def _worker(rank, world, port, scene, nsteps, rebalance_every, out_path, overlap
         got = slab.gather(len(a))
         if rank == 0:
             np.save(out_path, got)
+            np.save(out_path + ".bounds.npy", np.array(slab.bounds))
     finally:
         dist.destroy_process_group()
 
@@ -63,6 +70,10 @@ def _scene(name):
         p, a = scenes.dam_break(36, 20)
         a["vel"][:, 0] = 4.0
         a["pos"][:, 0] += np.float32(2.0)
+        return p, a
+    if name == "wide":  # 96 x 24: 24 grid columns of ~96 particles
+        p, a = scenes.dam_break(96, 24)
+        a["vel"][:, 0] = 2.0
         return p, a
     raise KeyError(name)
 
@@ -77,6 +88,36 @@ def test_slab_equals_single_domain(tmp_path, world, scene, nsteps, rebalance_eve
     params, a = _scene(scene)
     want = orc.Oracle().step_cells(params, a.copy(), nsteps)
     assert orc.same_bits(got, want)
+
+
+def test_large_boundary_shift_fits_the_handover_message(tmp_path):
+    """A rebalance may move a boundary by almost a whole neighbour slab; the first exchange afterwards hands all those
+    columns over in one message, which is sized for it from the histogram (handover_caps).  4 slabs that start 3
+    columns wide each (all the rest with the last rank), small column populations (24 rows: no floor hides anything --
+    the fake backend fails on the first record beyond a message's capacity)."""
+    out = str(tmp_path / "got.npy")
+    world, nsteps = 4, 12
+    mp.spawn(_worker, args=(world, _free_port(), "wide", nsteps, 3, out, "1", True), nprocs=world, join=True)
+    got = np.load(out)
+    params, a = _scene("wide")
+    want = orc.Oracle().step_cells(params, a.copy(), nsteps)
+    assert orc.same_bits(got, want)
+    b = np.load(out + ".bounds.npy")
+    assert b[3] > 15  # (from 9: boundaries move one neighbour's width at a time, the last one first)
+
+
+def test_message_sizes_from_the_histogram():
+    hist = np.zeros(60, np.int64)
+    hist[:40] = 100
+    hist[20] = 400  # a full column next to boundary 2
+    bounds = [0, 10, 21, 40, 60]
+    caps = steady_caps(hist, bounds, margin=1.25, floor=16)
+    assert caps[0] == 0 and caps[-1] == 0
+    assert caps[1] == int(1.25 * 2 * 100) and caps[2] == int(1.25 * 2 * 400) and caps[3] == int(1.25 * 2 * 100)
+    new = [0, 10, 30, 40, 60]  # boundary 2 moves right by 9 columns: columns 19 .. 31 travel
+    first = handover_caps(hist, bounds, new, steady_caps(hist, new, margin=1.25, floor=16))
+    need = int(hist[19:32].sum())
+    assert first[2] >= need and first[1] == steady_caps(hist, new, margin=1.25, floor=16)[1]
 
 
 def test_balanced_bounds():
