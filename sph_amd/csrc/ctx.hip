@@ -201,6 +201,7 @@ static void ctx_configure(SphCtx* c, const SphParams& p, const SphDerived& d, in
         if (const char* e = getenv("SPHHIP_FAST_DIV")) c->fast_div = c->fast_div && atoi(e) != 0;
     }
     if (const char* e = getenv("SPHHIP_USE_MASKS")) c->use_masks = atoi(e) != 0;
+    if (const char* e = getenv("SPHHIP_ZERO_P")) c->zero_p = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_GRAPH")) c->graph_off = atoi(e) == 0;
     if (const char* e = getenv("SPHHIP_SMALL_GRID")) c->small_grid = atoi(e) != 0;
     if (const char* e = getenv("SPHHIP_RANK_BIG")) c->rank_big = atoi(e) != 0;
@@ -667,7 +668,7 @@ static std::vector<uint64_t> step_sig(const SphCtx* c, float mx, float my, float
             (uint64_t)c->cell_cur, (uint64_t)c->n_slot, (uint64_t)c->n, (uint64_t)c->tile_cells, (uint64_t)c->pair_cap,
             (uint64_t)c->pair_threads, (uint64_t)c->grid_valid, (uint64_t)c->counts_valid, (uint64_t)c->slice_valid,
             (uint64_t)c->tiles_valid, (uint64_t)c->cell_next_zeroed, (uint64_t)c->mask_tile_cells, (uint64_t)c->mask_cap,
-            (uint64_t)c->tab_clo, (uint64_t)c->tab_chi, (uint64_t)c->use_masks, (uint64_t)c->fast_div,
+            (uint64_t)c->tab_clo, (uint64_t)c->tab_chi, (uint64_t)c->use_masks, (uint64_t)c->fast_div, (uint64_t)c->zero_p,
             (uint64_t)(dd != 0), (uint64_t)(df != 0), f(mx), f(my), f(strength)};
 }
 

@@ -538,7 +538,16 @@ __global__ __launch_bounds__(THREADS) void k_density(DevConsts c, const float2* 
 // correctly rounded sqrt of either is <= h.  (A NaN r_len fails `>` as well.)
 // FAST: divisions through exact_div.h (operands checked to be in the safe range when the tile was
 // staged); otherwise hipcc's generic correctly rounded `/`.  Same results bit for bit.
-template <int U, bool FAST>
+// ZEROP (only with FAST): the tile was staged with every pressure -- the candidates', hence also the own particles' --
+// equal to +0, and the pressure term is left out: pt = (+0 + +0) / (2 rho_j) = +0 (rho_j > 0 in the safe range), so
+// pressureForce = ((-m) * pt) * grad = +-0 in both components (grad is finite: zeroed for r_len <= 1e-6, at most
+// spiky * h^2 / 1e-6 otherwise), and (+-0 + a) + b == a + b unless a and b are both zeros, when only the sign of the
+// zero term can differ -- which cannot change the sum, by the same argument as for the guards below (the sum starts
+// at +0 and is never -0).  The spiky gradient (sph.cpp:15-20) is used by the pressure term alone and goes with it:
+// one division by r_len, one by rho_j and ten multiplications / additions fewer per pair.  Every BASELINE scene runs
+// here (densities far below REST_DENSITY: P = max(0, K (rho - rho0)) = +0 throughout); golden F5 (dense block, P > 0)
+// and the reference box keep the general instantiation busy.  SPHHIP_ZERO_P=0 switches the shortcut off.
+template <int U, bool FAST, bool ZEROP = false>
 __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx)[U], const float (&ry)[U],
                                             const float (&r2)[U], float pres_i, float vix, float viy,
                                             const float4 (&aj)[U] /* vx, vy, rho, P of j */,
@@ -556,14 +565,16 @@ __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx
         for (int u = 0; u < U; u++) r_len[u] = sph_sqrt_core(fmaxf(r2[u], SPH_SQRT_LO), yr[u]);  // sph.cpp:67
 #pragma unroll
         for (int u = 0; u < U; u++) inv_r[u] = sph_rcp_core(r_len[u], yr[u]);  // 1.0f / r_len, sph.cpp:31
+        if (!ZEROP) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            float term = c.h - r_len[u];
-            gcoeff[u] = sph_div_core(c.spiky * term * term, r_len[u], yr[u]);  // sph.cpp:17-18
+            for (int u = 0; u < U; u++) {
+                float term = c.h - r_len[u];
+                gcoeff[u] = sph_div_core(c.spiky * term * term, r_len[u], yr[u]);  // sph.cpp:17-18
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)  // (P_i + P_j) / (2 rho_j) == ((P_i + P_j) / rho_j) / 2 exactly in the safe range;
+                pt[u] = sph_div_core(pres_i + aj[u].w, aj[u].z, yd[u]);  // the 1/2 is folded into neg_mass below, sph.cpp:69
         }
-#pragma unroll
-        for (int u = 0; u < U; u++)  // (P_i + P_j) / (2 rho_j) == ((P_i + P_j) / rho_j) / 2 exactly in the safe range;
-            pt[u] = sph_div_core(pres_i + aj[u].w, aj[u].z, yd[u]);  // the 1/2 is folded into neg_mass below, sph.cpp:69
 #pragma unroll
         for (int u = 0; u < U; u++) {
             float lap = c.visc_lap * (c.h - r_len[u]);               // sph.cpp:23-26, see note (*)
@@ -595,6 +606,17 @@ __device__ __forceinline__ void force_terms(const DevConsts& c, const float (&rx
         float sr12 = sr6 * sr6;
         float inv_r2 = inv_r[u] * inv_r[u];
         lcoeff[u] = c.lj24 * (2.0f * sr12 - sr6) * inv_r2;
+    }
+    if (ZEROP) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float relx = aj[u].x - vix, rely = aj[u].y - viy;  // sph.cpp:71
+            bool zero_lj = (r_len[u] >= c.lj_cut) || (r_len[u] < 1e-6f);  // sph.cpp:30
+            float lc = zero_lj ? 0.0f : lcoeff[u];
+            fx[u] = visc[u] * relx + lc * rx[u];  // sph.cpp:74-75 without the (+-0) pressure term
+            fy[u] = visc[u] * rely + lc * ry[u];
+        }
+        return;
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -804,7 +826,7 @@ struct PairGroup {
     float4 pq[FORCE_HEAVY_UNROLL];   // pos.x, pos.y, yd, -
 };
 
-template <int THREADS>
+template <int THREADS, bool ZEROP>
 __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec* s_rec, uint32_t* s_mask,
                                               const uint32_t* __restrict__ mask_col, int n_max, int lo, int nw,
                                               int self, float2 pi, float2 vi, float pres_i, float& fx, float& fy, int tix) {
@@ -855,7 +877,7 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
             ry[u] = pi.y - g.pq[u].y;
             r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
         }
-        force_terms<U, true>(c, rx, ry, r2, pres_i, vi.x, vi.y, g.aux, yd, tx, ty);
+        force_terms<U, true, ZEROP>(c, rx, ry, r2, pres_i, vi.x, vi.y, g.aux, yd, tx, ty);
 #pragma unroll
         for (int u = 0; u < U; u++) {  // same order as the sequential sum
             fx += tx[u];
@@ -973,7 +995,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
     __syncthreads();
     STAMP(1);  // table ready
 
-    bool fast = false, by_mask = false;
+    bool fast = false, by_mask = false, zero_p = false;
     if (use_lds) {
         // the lane's mask words go to its LDS slots, s_mask[w * THREADS + tix] (read back by the same lane only)
         if (nmask) {
@@ -981,11 +1003,13 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
             for (int k = 0; k < PAIR_MASK_WORDS; k++)
                 if (k < nw_tile) s_mask[k * THREADS + tix] = mw[k];
         }
-        int flags = allow_fast ? 0 : 1;  // bit 0: an operand outside exact_div.h's safe range; bit 1: no masks
+        // bit 0: an operand outside exact_div.h's safe range; bit 1: no masks; bit 2: a pressure that is not +0
+        int flags = ((allow_fast & 1) ? 0 : 1) | ((allow_fast & 2) ? 0 : 4);
         if (!nmask) flags |= 2;          // k_density's masks: only if no candidate is invalid or non-finite
         auto stage = [&](int dst, float2 q, float2 w, float dj, float pj, uint32_t idj) {
             // exact_div.h is used only if every density / pressure of the tile is in its safe range
             flags |= (dj == 0.0f || !sph_safe_operand(dj) || !sph_safe_operand(pj)) ? 1 : 0;
+            flags |= __float_as_uint(pj) ? 4 : 0;  // (-0 counts as a pressure: the shortcut is argued for +0 only)
             // `!particles[j].valid` (sph.cpp:63): an invalid j is staged at +inf so that
             // r2 = +inf >= H*H skips it with the same compare that skips far particles.
             flags |= (!(fabsf(q.x) < inf) || !(fabsf(q.y) < inf) || (idj & SPH_INVALID_BIT)) ? 2 : 0;
@@ -1021,6 +1045,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
         const int all = *s_flags;
         fast = (all & 1) == 0;
         by_mask = fast && (all & 2) == 0;
+        zero_p = (all & 4) == 0;
         if (long_tile && !by_mask) {
             // the masks cannot be used after all (an operand outside the safe range, an invalid or non-finite candidate)
             // and the scan path's byte queue does not reach beyond FORCE_MAX_RANGE: the way of the dense sub-tiles
@@ -1067,12 +1092,19 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
                 // first pass's word pointer a compile-time null it costs nothing (1.78 -> 1.77 ms there, the evolved
                 // 1M dam break with its 8 long tiles 0.274 -> 0.258 ms per step).
                 const int nw_i = (hi - j + 31) >> 5;
-                force_by_mask<THREADS>(c, s_rec, s_mask, nullptr, n_max, j, min(nw_i, PAIR_MASK_WORDS), self, pi, vi, pres_i, fx, fy, tix);
+                if (zero_p)
+                    force_by_mask<THREADS, true>(c, s_rec, s_mask, nullptr, n_max, j, min(nw_i, PAIR_MASK_WORDS), self, pi, vi, pres_i, fx, fy, tix);
+                else
+                    force_by_mask<THREADS, false>(c, s_rec, s_mask, nullptr, n_max, j, min(nw_i, PAIR_MASK_WORDS), self, pi, vi, pres_i, fx, fy, tix);
                 if (long_tile) {  // (the array of words 8..13: its address from device memory, only when it is needed)
                     const ForceExtraDev* xp = cdev;
                     asm volatile("" : "+s"(xp) : : "memory");
-                    force_by_mask<THREADS>(c, s_rec, s_mask, xp->nmask_hi + s, n_max, j + FORCE_MAX_RANGE,
-                                           min(max(nw_i - PAIR_MASK_WORDS, 0), PAIR_MASK_WORDS), self, pi, vi, pres_i, fx, fy, tix);
+                    const uint32_t* hi_words = xp->nmask_hi + s;
+                    const int nw_hi = min(max(nw_i - PAIR_MASK_WORDS, 0), PAIR_MASK_WORDS);
+                    if (zero_p)
+                        force_by_mask<THREADS, true>(c, s_rec, s_mask, hi_words, n_max, j + FORCE_MAX_RANGE, nw_hi, self, pi, vi, pres_i, fx, fy, tix);
+                    else
+                        force_by_mask<THREADS, false>(c, s_rec, s_mask, hi_words, n_max, j + FORCE_MAX_RANGE, nw_hi, self, pi, vi, pres_i, fx, fy, tix);
                 }
             } else if (fast)
                 force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
@@ -1880,7 +1912,7 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
         sph_phase_begin(c, SPHHIP_PH_FORCE_INTERIOR, c->side_stream);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->side_stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
                            c->cell_start, pout, vout, q, il, ih, 0, 0, c->pair_cap, c->col_lo, c->col_hi, mx, my, strength,
-                           c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink, c->d_consts);
+                           (c->fast_div ? 1 : 0) | (c->zero_p ? 2 : 0), masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink, c->d_consts);
         LAUNCH_CHECK();
         sph_phase_end(c, SPHHIP_PH_FORCE_INTERIOR, c->side_stream);
         HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
@@ -1888,7 +1920,7 @@ int sph_force_launch(SphCtx* c, float mx, float my, float strength, bool fuse_in
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(th), lds, c->stream, c->dc, pin, vin, c->rho, c->prs, c->idv, c->keys,
                        c->cell_start, pout, vout, q, lo, hi, skip_lo, skip_hi, c->pair_cap, c->col_lo, c->col_hi,
-                       mx, my, strength, c->fast_div ? 1 : 0, masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink, c->d_consts);
+                       mx, my, strength, (c->fast_div ? 1 : 0) | (c->zero_p ? 2 : 0), masks_ok ? c->nmask : (const uint32_t*)nullptr, c->n_max, sink, c->d_consts);
     LAUNCH_CHECK();
     if (sink.mode & 1) {
         auto dkern = tp ? (fuse_integrate ? k_force_dense_tp<true> : k_force_dense_tp<false>)

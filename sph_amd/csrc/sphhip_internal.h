@@ -107,6 +107,7 @@ struct SphCtx {
     bool small_grid = true;     // SPHHIP_SMALL_GRID=0: never the one-workgroup grid build (grid.hip: k_grid_small)
     bool lazy_pack = true;      // SPHHIP_LAZY_PACK=0: sphhip_pack_halo_async always compacts
     bool use_masks = true;      // SPHHIP_USE_MASKS=0: k_force always scans
+    bool zero_p = true;         // SPHHIP_ZERO_P=0: k_force never drops the pressure term of an all-zero-pressure tile
 
     // grid
     uint32_t *keys = nullptr, *keys2 = nullptr;  // cell key per slot (ping-pong during the sort)

@@ -9,6 +9,7 @@ stand-alone phases -- and on a 2-rank slab run (the switches that touch the halo
   SPHHIP_SMALL_GRID=0   never the one-workgroup grid build
   SPHHIP_LAZY_PACK=0    the halo pack always compacts the state
   SPHHIP_TILE_LIST_FUSED=0  the pair kernels' work list from a launch of its own instead of k_cell_scatter's head workgroups
+  SPHHIP_ZERO_P=0       k_force keeps the pressure term (and the spiky gradient) on tiles whose pressures are all +0
 """
 import os
 
@@ -26,7 +27,7 @@ O = orc.Oracle()
 P = O.default_params()
 
 SWITCHES = [("SPHHIP_GRID", "radix"), ("SPHHIP_USE_MASKS", "0"), ("SPHHIP_FAST_DIV", "0"), ("SPHHIP_SMALL_GRID", "0"),
-            ("SPHHIP_LAZY_PACK", "0"), ("SPHHIP_TILE_LIST_FUSED", "0")]
+            ("SPHHIP_LAZY_PACK", "0"), ("SPHHIP_TILE_LIST_FUSED", "0"), ("SPHHIP_ZERO_P", "0")]
 
 
 def _scenes():
@@ -62,6 +63,38 @@ def test_switch_keeps_every_bit(monkeypatch, var, val):
             s.upload(d)
             s.computeForces((1.0, 1.0), 50000.0)
             assert orc.same_bits(s.download(), O.forces_cells(params, d.copy(), (1.0, 1.0), 50000.0)), (var, name, "forces")
+
+
+def _mixed_pressure_scene():
+    """A dam-break miniature (zero pressure everywhere: densities of ~100) with a block at a tenth of the spacing on top
+    of it (densities above REST_DENSITY, P > 0): tiles of both kinds in one launch, and tiles that hold both."""
+    params, a = scenes.dam_break(64)
+    blk = scenes._block(30, 30, np.float32(params.h / 40.0), np.float32(params.xmin + 1.0), np.float32(params.ymin + 2.45))
+    b = np.zeros(len(a) + len(blk), a.dtype)
+    b[:len(a)] = a
+    b[len(a):] = blk
+    b["vel"][::7, 0] = 0.25
+    b["vel"][::5, 1] = -0.5
+    return params, b
+
+
+@pytest.mark.parametrize("zero_p", ["1", "0"])
+def test_zero_pressure_shortcut_on_a_mixed_scene(monkeypatch, zero_p):
+    """k_force leaves the pressure term (and the spiky gradient it alone uses) out on tiles staged with every pressure
+    +0: bit for bit the same sum (pairs.hip: force_terms<ZEROP>).  Checked where both kinds of tile meet."""
+    monkeypatch.setenv("SPHHIP_ZERO_P", zero_p)
+    params, a = _mixed_pressure_scene()
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.computeDensityPressure()
+        d = s.download()
+        n_p = int((d["pressure"] > 0).sum())
+        assert 100 < n_p < len(a) // 4, n_p  # some pressure, mostly none
+        assert orc.same_bits(d, O.density_cells(params, a.copy())[0])
+        for nsteps in (1, 6):
+            s.upload(a)
+            s.stepSimulation(nsteps=nsteps)
+            assert orc.same_bits_nan(s.download(), O.step_cells(params, a.copy(), nsteps)), nsteps
 
 
 @pytest.mark.parametrize("var,val", [("SPHHIP_LAZY_PACK", "0"), ("SPHHIP_GRID", "radix"), ("SPHHIP_USE_MASKS", "0"),

@@ -5,6 +5,6 @@ for v in "$@"; do
   lib=variants/$v/libsphhip.so
   [ "$v" = "base" ] && lib=sph_amd/libsphhip.so
   out=$(SPHHIP_LIB=$PWD/$lib timeout -k 10 120 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra-scenes ${AB_ARGS:-} 2>/dev/null | tail -1)
-  echo "$v => $(echo "$out" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); p=d["phases_ms_per_step"]; print("value %.3e ms %.4f force %.4f density %.4f grid %.4f (hash %.4f sort %.4f cells %.4f reorder %.4f)"%(d["value"],d["ms_per_step"],p["force"],p["density"],p["hash"]+p["sort"]+p["cells"]+p["reorder"],p["hash"],p["sort"],p["cells"],p["reorder"]))')"
+  echo "$v => $(echo "$out" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); p=d["phases_ms_per_step"]; print("value %.3e median %.3e ms %.4f force %.4f density %.4f grid %.4f (hash %.4f sort %.4f cells %.4f reorder %.4f)"%(d["value"],d.get("value_median",0),d["ms_per_step"],p["force"],p["density"],p["hash"]+p["sort"]+p["cells"]+p["reorder"],p["hash"],p["sort"],p["cells"],p["reorder"]))')"
 done
 done
