@@ -111,6 +111,22 @@ def cpu_baseline():
             "value": 8192 * 2 / dt, "unit": "particle-updates/s", "cores": 1, "kind": "reference",
             "sample": "reference SPH/sph.cpp compiled unmodified (oracle/_ref), its own lattice scene N=8192, 2 steps, %.1f s" % dt,
         }
+    # the reference's own harness and unit (X_performance_test: steps per second on its default scene, N = 1024,
+    # SPH/serial_main.cpp:120-147 / main.cpp:115,127) through the oracle-side dispatcher, shortened to 2 runs x 50 steps
+    exe = os.path.join(ROOT, "oracle", "sph_cpu_main")
+    if os.path.exists(exe):
+        ups = {}
+        for method, label in (("serial", "Serial"), ("omp", "OpenMP")):
+            try:
+                r = subprocess.run([exe, "--method", method, "--n", "1024", "--runs", "2", "--steps", "50"], capture_output=True, text=True, timeout=120)
+                for line in r.stdout.splitlines():
+                    if line.startswith(label + " Average UPS:"):
+                        ups[label + " Average UPS"] = float(line.split(":")[1])
+            except Exception:
+                pass
+        if ups:
+            ups["sample"] = "oracle/sph_cpu_main --n 1024 --runs 2 --steps 50 (reference default scene, its UPS unit; OpenMP on %d threads)" % cores
+            extra["cpu_reference_menu"] = ups
     return base, extra
 
 

@@ -88,6 +88,27 @@ struct __align__(16) PairRec {
     float pad;
 };
 
+// Two LDS layouts of the staged records.  !SPLIT: an array of PairRec (the dense kernels).  SPLIT (the tuned force
+// kernel): the two 16-byte halves in arrays of their own, aux[cap] then pq[cap] (`pq_off` = 16 * cap bytes apart).  A
+// popped candidate is read by two 16-byte loads at a lane-varying record index; with 32-byte records either load can
+// only ever touch every other 16-byte bank group, a two-way conflict built into the layout (SQ_LDS_BANK_CONFLICT was
+// 65 % of the LDS cycles and the LDS pipe 70 % busy once the zero-pressure shortcut had thinned the arithmetic out);
+// with the halves apart consecutive records fall into consecutive bank groups.
+template <bool SPLIT>
+__device__ __forceinline__ const char* rec_at(const PairRec* base, int r) {
+    return reinterpret_cast<const char*>(base) + r * (SPLIT ? 16 : 32);
+}
+template <bool SPLIT>
+__device__ __forceinline__ const float4* rec_pq(const char* at, int pq_off) {
+    return reinterpret_cast<const float4*>(at + (SPLIT ? pq_off : 16));
+}
+template <bool SPLIT>
+__device__ __forceinline__ void rec_store(PairRec* base, int r, int pq_off, float4 aux, float2 pos, float yd) {
+    char* at = reinterpret_cast<char*>(base) + r * (SPLIT ? 16 : 32);
+    *reinterpret_cast<float4*>(at) = aux;
+    *reinterpret_cast<float4*>(at + (SPLIT ? pq_off : 16)) = make_float4(pos.x, pos.y, yd, 0.0f);
+}
+
 struct TileGeom {
     int col, cy0, cy1, ylo, yhi, own_lo, own_hi, ncells, total;
 };
@@ -717,10 +738,10 @@ __device__ __forceinline__ void integrate_one(const DevConsts& c, float2& p, flo
 // ---------------------------------------------------------------------------------------------
 // Heavy phase of one round: evaluates the qn queued pairs of every lane (byte offsets from `lo` in
 // s_q), FORCE_HEAVY_UNROLL at a time, in queue order.
-template <int THREADS, bool FAST, bool WIN, int U = FORCE_HEAVY_UNROLL>
+template <int THREADS, bool FAST, bool WIN, int U = FORCE_HEAVY_UNROLL, bool SPLIT = false>
 __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s_rec,
                                             uint8_t* s_q, int qn, int lo, int self_off, float2 pi, float2 vi,
-                                            float pres_i, float& fx, float& fy, int tix) {
+                                            float pres_i, float& fx, float& fy, int tix, int pq_off = 0) {
     const int tid = tix;
     // WIN: the range is one window of a longer one and the particle itself may lie outside it, so there is no
     // +0 term to pad with: exhausted slots evaluate the window's first record and are left out of the sum.
@@ -744,9 +765,9 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const float4* rec = reinterpret_cast<const float4*>(s_rec + jj[u]);
-            aj[u] = rec[0];
-            const float4 q = rec[1];  // pos.x, pos.y, yd
+            const char* at = rec_at<SPLIT>(s_rec, jj[u]);
+            aj[u] = *reinterpret_cast<const float4*>(at);
+            const float4 q = *rec_pq<SPLIT>(at, pq_off);  // pos.x, pos.y, yd
             yd[u] = q.z;
             rx[u] = pi.x - q.x;
             ry[u] = pi.y - q.y;
@@ -781,10 +802,10 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
 // !FAST keeps the reference's `j == i` test (sph.cpp:63) and a predicated accumulation.
 // (U pairs in flight per lane, Q queued per round: the tuned kernels run many waves per SIMD and do best with
 // 2 and 8; the dense kernel runs one wave per SIMD and wants the instruction-level parallelism of 8 and 24)
-template <int THREADS, bool FAST, bool WIN = false, int U = FORCE_HEAVY_UNROLL, int Q = FORCE_Q>
+template <int THREADS, bool FAST, bool WIN = false, int U = FORCE_HEAVY_UNROLL, int Q = FORCE_Q, bool SPLIT = false>
 __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* s_rec,
                                              uint8_t* s_q, int j, int hi, int self, float2 pi, float2 vi,
-                                             float pres_i, float& fx, float& fy, int tix) {
+                                             float pres_i, float& fx, float& fy, int tix, int pq_off = 0) {
     const int tid = tix;
     // the queue holds byte offsets from the start of the lane's range (ranges are <= FORCE_MAX_RANGE long)
     const int lo = j;
@@ -795,7 +816,10 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* 
             if ((j < hi) && (qn < Q)) {
                 float2 q[FORCE_SCAN_UNROLL];
 #pragma unroll
-                for (int u = 0; u < FORCE_SCAN_UNROLL; u++) q[u] = s_rec[j + u].pos;  // may run into the row sentinels
+                for (int u = 0; u < FORCE_SCAN_UNROLL; u++) {  // may run into the row sentinels
+                    const float4* pq = rec_pq<SPLIT>(rec_at<SPLIT>(s_rec, j + u), pq_off);
+                    q[u] = *reinterpret_cast<const float2*>(pq);
+                }
 #pragma unroll
                 for (int u = 0; u < FORCE_SCAN_UNROLL; u++) {
                     float rx = pi.x - q[u].x, ry = pi.y - q[u].y;
@@ -810,7 +834,7 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* 
                 j += FORCE_SCAN_UNROLL;
             }
         }
-        force_heavy<THREADS, FAST, WIN, U>(c, s_rec, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy, tix);
+        force_heavy<THREADS, FAST, WIN, U, SPLIT>(c, s_rec, s_q, qn, lo, self_off, pi, vi, pres_i, fx, fy, tix, pq_off);
     }
 }
 
@@ -829,7 +853,8 @@ struct PairGroup {
 template <int THREADS, bool ZEROP>
 __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec* s_rec, uint32_t* s_mask,
                                               const uint32_t* __restrict__ mask_col, int n_max, int lo, int nw,
-                                              int self, float2 pi, float2 vi, float pres_i, float& fx, float& fy, int tix) {
+                                              int self, float2 pi, float2 vi, float pres_i, float& fx, float& fy, int tix,
+                                              int pq_off) {
     constexpr int U = FORCE_HEAVY_UNROLL;
     const int tid = tix;
     // The lane's mask words are in LDS, s_mask[w * THREADS + tid] (force_tile puts the first batch's there
@@ -841,12 +866,29 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
             if (k < nw) s_mask[k * THREADS + tid] = mask_col[(size_t)k * n_max];
     }
     int w = 0;
-    // byte offset (32-byte records) of the candidate in the top bit of the current word
-    int base32 = lo * (int)sizeof(PairRec);
-    const int self32 = self * (int)sizeof(PairRec);
+    // LDS address of the candidate in the top bit of the current word, and of the particle itself (the image's base
+    // is part of both: added once here, not after every pop)
+    const char* base_p = rec_at<true>(s_rec, lo);
+    const char* const self_p = rec_at<true>(s_rec, self);
     uint32_t m = 0, m_next = 0;
     if (nw > 0) m = s_mask[tid];
     if (nw > 1) m_next = s_mask[THREADS + tid];
+    // Trips of the wave: the lane with the most neighbours sets them (its pops, FORCE_HEAVY_UNROLL per trip).  Counting
+    // the bits up front makes the loop counter a scalar: the per-trip vote "any lane with a bit left?" (two compares,
+    // an or and the vote itself) is gone.
+    // (a pop that finds its word empty moves on to the next word once; if that one is empty too the pop is spent on the
+    // particle itself: every empty word behind the first costs the lane one pop)
+    int left = 0;
+#pragma unroll
+    for (int k = 0; k < PAIR_MASK_WORDS; k++)
+        if (k < nw) {
+            const uint32_t wk = s_mask[k * THREADS + tid];
+            left += __builtin_popcount(wk) + ((k > 0 && wk == 0) ? 1 : 0);
+        }
+    int trips = (left + U - 1) / U;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) trips = max(trips, __shfl_xor(trips, d, 64));
+    trips = __builtin_amdgcn_readfirstlane(trips);
     // pops the next U set bits of the lane and starts the LDS reads of those records
     auto fetch = [&](PairGroup& g) {
 #pragma unroll
@@ -856,16 +898,18 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
             // more issue slots than the three operations save.)
             if (m == 0 && w + 1 < nw) {
                 w++;
-                base32 += 32 * (int)sizeof(PairRec);
+                base_p += 32 * 16;  // 32 records on, split layout
                 m = m_next;
                 if (w + 1 < nw) m_next = s_mask[(w + 1) * THREADS + tid];
             }
-            const int b = __builtin_clz(m | 1u);  // (m == 0: any value, the slot evaluates the particle itself)
-            const int off = (m != 0) ? base32 + (b << 5) : self32;
-            m &= 0x7fffffffu >> b;
-            const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + off);
-            g.aux[u] = rec[0];
-            g.pq[u] = rec[1];
+            // v_ffbh_u32 of 0 is -1: shifted and added it gives an address that is not used (m == 0: the slot evaluates
+            // the particle itself), and 0x7fffffff >> (-1 & 31) = 0 leaves m at 0
+            int b;
+            asm("v_ffbh_u32 %0, %1" : "=v"(b) : "v"(m));
+            const char* at = (m != 0) ? base_p + (b << 4) : self_p;
+            m &= 0x7fffffffu >> (b & 31);
+            g.aux[u] = *reinterpret_cast<const float4*>(at);
+            g.pq[u] = *rec_pq<true>(at, pq_off);
         }
     };
     auto eval = [&](const PairGroup& g) {
@@ -887,7 +931,7 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
     // (A two-register-set software pipeline -- pops and LDS reads of the next group issued before the
     // current one is evaluated -- was measured: 30 more VGPRs, spills at 4 waves per SIMD, 1 % slower.)
     PairGroup g;
-    while (__any(m != 0 || w + 1 < nw)) {
+    for (int t = 0; t < trips; t++) {
         fetch(g);
         eval(g);
     }
@@ -953,6 +997,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
     const float inf = __builtin_inff();
     int* s_flags = s_wave + 7;
     uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_q);
+    const int pq_off = cap * 16;  // split record layout: aux[cap], pq[cap] (rec_at / rec_pq)
 
     // ---- every global load of the prologue
     int g0, g1;
@@ -1014,12 +1059,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
             // r2 = +inf >= H*H skips it with the same compare that skips far particles.
             flags |= (!(fabsf(q.x) < inf) || !(fabsf(q.y) < inf) || (idj & SPH_INVALID_BIT)) ? 2 : 0;
             if (idj & SPH_INVALID_BIT) q = make_float2(inf, inf);
-            PairRec rec;
-            rec.aux = make_float4(w.x, w.y, dj, pj);
-            rec.pos = q;
-            rec.yd = sph_rcp_refined(dj);
-            rec.pad = 0.0f;
-            s_rec[dst] = rec;
+            rec_store<true>(s_rec, dst, pq_off, make_float4(w.x, w.y, dj, pj), q, sph_rcp_refined(dj));
         };
 #pragma unroll
         for (int b = 0; b < PAIR_STAGE_BATCH; b++)
@@ -1033,12 +1073,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
         }
         for (int t = tix; t < (g.ncells / 3) * PAIR_ROW_PAD; t += THREADS) {
             int idx = s_off[3 * (t / PAIR_ROW_PAD) + 3] - PAIR_ROW_PAD + (t % PAIR_ROW_PAD);
-            PairRec rec;
-            rec.aux = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-            rec.pos = make_float2(inf, inf);
-            rec.yd = 1.0f;
-            rec.pad = 0.0f;
-            s_rec[idx] = rec;
+            rec_store<true>(s_rec, idx, pq_off, make_float4(0.0f, 0.0f, 1.0f, 0.0f), make_float2(inf, inf), 1.0f);
         }
         if (flags) atomicOr(s_flags, flags);
         __syncthreads();
@@ -1093,23 +1128,23 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
                 // 1M dam break with its 8 long tiles 0.274 -> 0.258 ms per step).
                 const int nw_i = (hi - j + 31) >> 5;
                 if (zero_p)
-                    force_by_mask<THREADS, true>(c, s_rec, s_mask, nullptr, n_max, j, min(nw_i, PAIR_MASK_WORDS), self, pi, vi, pres_i, fx, fy, tix);
+                    force_by_mask<THREADS, true>(c, s_rec, s_mask, nullptr, n_max, j, min(nw_i, PAIR_MASK_WORDS), self, pi, vi, pres_i, fx, fy, tix, pq_off);
                 else
-                    force_by_mask<THREADS, false>(c, s_rec, s_mask, nullptr, n_max, j, min(nw_i, PAIR_MASK_WORDS), self, pi, vi, pres_i, fx, fy, tix);
+                    force_by_mask<THREADS, false>(c, s_rec, s_mask, nullptr, n_max, j, min(nw_i, PAIR_MASK_WORDS), self, pi, vi, pres_i, fx, fy, tix, pq_off);
                 if (long_tile) {  // (the array of words 8..13: its address from device memory, only when it is needed)
                     const ForceExtraDev* xp = cdev;
                     asm volatile("" : "+s"(xp) : : "memory");
                     const uint32_t* hi_words = xp->nmask_hi + s;
                     const int nw_hi = min(max(nw_i - PAIR_MASK_WORDS, 0), PAIR_MASK_WORDS);
                     if (zero_p)
-                        force_by_mask<THREADS, true>(c, s_rec, s_mask, hi_words, n_max, j + FORCE_MAX_RANGE, nw_hi, self, pi, vi, pres_i, fx, fy, tix);
+                        force_by_mask<THREADS, true>(c, s_rec, s_mask, hi_words, n_max, j + FORCE_MAX_RANGE, nw_hi, self, pi, vi, pres_i, fx, fy, tix, pq_off);
                     else
-                        force_by_mask<THREADS, false>(c, s_rec, s_mask, hi_words, n_max, j + FORCE_MAX_RANGE, nw_hi, self, pi, vi, pres_i, fx, fy, tix);
+                        force_by_mask<THREADS, false>(c, s_rec, s_mask, hi_words, n_max, j + FORCE_MAX_RANGE, nw_hi, self, pi, vi, pres_i, fx, fy, tix, pq_off);
                 }
             } else if (fast)
-                force_rounds<THREADS, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
+                force_rounds<THREADS, true, false, FORCE_HEAVY_UNROLL, FORCE_Q, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix, pq_off);
             else
-                force_rounds<THREADS, false>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix);
+                force_rounds<THREADS, false, false, FORCE_HEAVY_UNROLL, FORCE_Q, true>(c, s_rec, s_q, j, hi, self, pi, vi, pres_i, fx, fy, tix, pq_off);
         } else if (have && valid) {
             for (int cc = 3 * r0; cc < 3 * r1 + 3; cc++) {
                 int gs = s_gs[cc], n = cand_count(s_off, cc);

@@ -201,3 +201,24 @@ def test_init_column_count_sqrt_double_vs_float():
     a = scenes.lattice((1 << 24) + 1)  # the double form: 4097 columns
     assert a["pos"][4096, 1] == a["pos"][0, 1] and a["pos"][4097, 1] < a["pos"][0, 1]
 
+
+
+def test_cpu_dispatcher_serial_and_openmp(tmp_path):
+    """oracle/sph_cpu_main: the reference menu's CPU entries (SPH/main.cpp:106-141) over the oracle, with the
+    X_performance_test protocol and output line (serial_main.cpp:120-147, main.cpp:115,127).  Test infrastructure: the
+    product's dispatcher refuses these methods.  Its serial run must land on the compiled reference's golden trajectory."""
+    import subprocess
+
+    exe = os.path.join(orc.ROOT, "oracle", "sph_cpu_main")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/sph_cpu_main not built (make -C oracle)")
+    dump = str(tmp_path / "s10.bin")
+    r = subprocess.run([exe, "--method", "serial", "--n", "1024", "--mode", "run", "--steps", "10", "--dump", dump],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(dump, dtype=G("f2_serial_traj_n1024")["s10"].dtype)
+    assert orc.same_bits(got, G("f2_serial_traj_n1024")["s10"])
+    for method, label in (("serial", "Serial"), ("omp", "OpenMP")):
+        r = subprocess.run([exe, "--method", method, "--n", "256", "--runs", "2", "--steps", "5"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and (label + " Average UPS: ") in r.stdout, r.stdout + r.stderr
+    assert subprocess.run([exe, "--method", "hip"], capture_output=True).returncode == 2
