@@ -89,24 +89,55 @@ struct __align__(16) PairRec {
 };
 
 // Two LDS layouts of the staged records.  !SPLIT: an array of PairRec (the dense kernels).  SPLIT (the tuned force
-// kernel): the two 16-byte halves in arrays of their own, aux[cap] then pq[cap] (`pq_off` = 16 * cap bytes apart).  A
-// popped candidate is read by two 16-byte loads at a lane-varying record index; with 32-byte records either load can
-// only ever touch every other 16-byte bank group, a two-way conflict built into the layout (SQ_LDS_BANK_CONFLICT was
-// 65 % of the LDS cycles and the LDS pipe 70 % busy once the zero-pressure shortcut had thinned the arithmetic out);
-// with the halves apart consecutive records fall into consecutive bank groups.
-template <bool SPLIT>
-__device__ __forceinline__ const char* rec_at(const PairRec* base, int r) {
-    return reinterpret_cast<const char*>(base) + r * (SPLIT ? 16 : 32);
+// kernel): three arrays, hot[cap] = {x, y, 1/rho~, rho} (16 bytes: everything the distance, the root and the
+// divisions by rho_j need), vel[cap] = {vx, vy} (8 bytes) and prs[cap] (4 bytes, not read at all on the zero-pressure
+// path); `hot_bytes` = 16 * cap.  A popped candidate is read at a lane-varying record index: with 32-byte records
+// either of the two 16-byte loads could only ever touch every other 16-byte bank group, a two-way conflict built
+// into the layout (SQ_LDS_BANK_CONFLICT was 65 % of the LDS cycles and the LDS pipe 70 % busy once the zero-pressure
+// shortcut had thinned the arithmetic out); apart, consecutive records fall into consecutive bank groups.
+// tools/ubench/lds_gather.hip, LDS cycles per wave and candidate at 4 workgroups per CU: 32-byte records 30.7, two
+// arrays of 16-byte halves 22.6, 16 + 8 bytes 18.5, no conflicts at all 13.1.
+struct RecVals {
+    float4 aux;  // vx, vy, rho, P (P = 0 where it was not read)
+    float2 pos;
+    float yd;
+};
+template <bool SPLIT, bool NEED_P>
+__device__ __forceinline__ RecVals rec_load(const PairRec* base, int r, int hot_bytes) {
+    RecVals v;
+    const char* b = reinterpret_cast<const char*>(base);
+    if (SPLIT) {
+        const float4 h = *reinterpret_cast<const float4*>(b + r * 16);
+        const float2 w = *reinterpret_cast<const float2*>(b + hot_bytes + r * 8);
+        const float p = NEED_P ? *reinterpret_cast<const float*>(b + hot_bytes + (hot_bytes >> 1) + r * 4) : 0.0f;
+        v.aux = make_float4(w.x, w.y, h.w, p);
+        v.pos = make_float2(h.x, h.y);
+        v.yd = h.z;
+    } else {
+        const float4* q = reinterpret_cast<const float4*>(b + r * 32);
+        v.aux = q[0];
+        const float4 t = q[1];
+        v.pos = make_float2(t.x, t.y);
+        v.yd = t.z;
+    }
+    return v;
 }
 template <bool SPLIT>
-__device__ __forceinline__ const float4* rec_pq(const char* at, int pq_off) {
-    return reinterpret_cast<const float4*>(at + (SPLIT ? pq_off : 16));
+__device__ __forceinline__ float2 rec_pos(const PairRec* base, int r) {
+    const char* b = reinterpret_cast<const char*>(base);
+    return *reinterpret_cast<const float2*>(b + (SPLIT ? r * 16 : r * 32 + 16));
 }
 template <bool SPLIT>
-__device__ __forceinline__ void rec_store(PairRec* base, int r, int pq_off, float4 aux, float2 pos, float yd) {
-    char* at = reinterpret_cast<char*>(base) + r * (SPLIT ? 16 : 32);
-    *reinterpret_cast<float4*>(at) = aux;
-    *reinterpret_cast<float4*>(at + (SPLIT ? pq_off : 16)) = make_float4(pos.x, pos.y, yd, 0.0f);
+__device__ __forceinline__ void rec_store(PairRec* base, int r, int hot_bytes, float4 aux, float2 pos, float yd) {
+    char* b = reinterpret_cast<char*>(base);
+    if (SPLIT) {
+        *reinterpret_cast<float4*>(b + r * 16) = make_float4(pos.x, pos.y, yd, aux.z);
+        *reinterpret_cast<float2*>(b + hot_bytes + r * 8) = make_float2(aux.x, aux.y);
+        *reinterpret_cast<float*>(b + hot_bytes + (hot_bytes >> 1) + r * 4) = aux.w;
+    } else {
+        *reinterpret_cast<float4*>(b + r * 32) = aux;
+        *reinterpret_cast<float4*>(b + r * 32 + 16) = make_float4(pos.x, pos.y, yd, 0.0f);
+    }
 }
 
 struct TileGeom {
@@ -765,12 +796,11 @@ __device__ __forceinline__ void force_heavy(const DevConsts& c, const PairRec* s
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const char* at = rec_at<SPLIT>(s_rec, jj[u]);
-            aj[u] = *reinterpret_cast<const float4*>(at);
-            const float4 q = *rec_pq<SPLIT>(at, pq_off);  // pos.x, pos.y, yd
-            yd[u] = q.z;
-            rx[u] = pi.x - q.x;
-            ry[u] = pi.y - q.y;
+            const RecVals q = rec_load<SPLIT, true>(s_rec, jj[u], pq_off);
+            aj[u] = q.aux;
+            yd[u] = q.yd;
+            rx[u] = pi.x - q.pos.x;
+            ry[u] = pi.y - q.pos.y;
             r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
         }
         force_terms<U, FAST>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, yd, tx, ty);
@@ -816,10 +846,7 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* 
             if ((j < hi) && (qn < Q)) {
                 float2 q[FORCE_SCAN_UNROLL];
 #pragma unroll
-                for (int u = 0; u < FORCE_SCAN_UNROLL; u++) {  // may run into the row sentinels
-                    const float4* pq = rec_pq<SPLIT>(rec_at<SPLIT>(s_rec, j + u), pq_off);
-                    q[u] = *reinterpret_cast<const float2*>(pq);
-                }
+                for (int u = 0; u < FORCE_SCAN_UNROLL; u++) q[u] = rec_pos<SPLIT>(s_rec, j + u);  // may run into the row sentinels
 #pragma unroll
                 for (int u = 0; u < FORCE_SCAN_UNROLL; u++) {
                     float rx = pi.x - q[u].x, ry = pi.y - q[u].y;
@@ -846,8 +873,7 @@ __device__ __forceinline__ void force_rounds(const DevConsts& c, const PairRec* 
 // Only for FAST tiles: the masks contain the particle itself.
 // One group of FORCE_HEAVY_UNROLL pairs as raw LDS records.
 struct PairGroup {
-    float4 aux[FORCE_HEAVY_UNROLL];  // vx, vy, rho, P
-    float4 pq[FORCE_HEAVY_UNROLL];   // pos.x, pos.y, yd, -
+    RecVals rec[FORCE_HEAVY_UNROLL];
 };
 
 template <int THREADS, bool ZEROP>
@@ -866,10 +892,7 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
             if (k < nw) s_mask[k * THREADS + tid] = mask_col[(size_t)k * n_max];
     }
     int w = 0;
-    // LDS address of the candidate in the top bit of the current word, and of the particle itself (the image's base
-    // is part of both: added once here, not after every pop)
-    const char* base_p = rec_at<true>(s_rec, lo);
-    const char* const self_p = rec_at<true>(s_rec, self);
+    int base_i = lo;  // record index of the candidate in the top bit of the current word
     uint32_t m = 0, m_next = 0;
     if (nw > 0) m = s_mask[tid];
     if (nw > 1) m_next = s_mask[THREADS + tid];
@@ -898,7 +921,7 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
             // more issue slots than the three operations save.)
             if (m == 0 && w + 1 < nw) {
                 w++;
-                base_p += 32 * 16;  // 32 records on, split layout
+                base_i += 32;
                 m = m_next;
                 if (w + 1 < nw) m_next = s_mask[(w + 1) * THREADS + tid];
             }
@@ -906,22 +929,23 @@ __device__ __forceinline__ void force_by_mask(const DevConsts& c, const PairRec*
             // the particle itself), and 0x7fffffff >> (-1 & 31) = 0 leaves m at 0
             int b;
             asm("v_ffbh_u32 %0, %1" : "=v"(b) : "v"(m));
-            const char* at = (m != 0) ? base_p + (b << 4) : self_p;
+            const int r = (m != 0) ? base_i + b : self;
             m &= 0x7fffffffu >> (b & 31);
-            g.aux[u] = *reinterpret_cast<const float4*>(at);
-            g.pq[u] = *rec_pq<true>(at, pq_off);
+            g.rec[u] = rec_load<true, !ZEROP>(s_rec, r, pq_off);
         }
     };
     auto eval = [&](const PairGroup& g) {
         float tx[U], ty[U], rx[U], ry[U], r2[U], yd[U];
+        float4 aj[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            yd[u] = g.pq[u].z;
-            rx[u] = pi.x - g.pq[u].x;
-            ry[u] = pi.y - g.pq[u].y;
+            aj[u] = g.rec[u].aux;
+            yd[u] = g.rec[u].yd;
+            rx[u] = pi.x - g.rec[u].pos.x;
+            ry[u] = pi.y - g.rec[u].pos.y;
             r2[u] = rx[u] * rx[u] + ry[u] * ry[u];
         }
-        force_terms<U, true, ZEROP>(c, rx, ry, r2, pres_i, vi.x, vi.y, g.aux, yd, tx, ty);
+        force_terms<U, true, ZEROP>(c, rx, ry, r2, pres_i, vi.x, vi.y, aj, yd, tx, ty);
 #pragma unroll
         for (int u = 0; u < U; u++) {  // same order as the sequential sum
             fx += tx[u];
@@ -997,7 +1021,7 @@ __device__ __forceinline__ void force_entry(const DevConsts& c, const float2* __
     const float inf = __builtin_inff();
     int* s_flags = s_wave + 7;
     uint32_t* s_mask = reinterpret_cast<uint32_t*>(s_q);
-    const int pq_off = cap * 16;  // split record layout: aux[cap], pq[cap] (rec_at / rec_pq)
+    const int pq_off = cap * 16;  // split record layout: hot[cap] (16 bytes), vel[cap] (8), prs[cap] (4): rec_load / rec_store
 
     // ---- every global load of the prologue
     int g0, g1;

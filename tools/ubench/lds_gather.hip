@@ -40,6 +40,22 @@ __global__ __launch_bounds__(256) void k(const uint16_t* idx, float* out) {
                 const float2 q0 = p[0], q1 = p[CAP], q2 = p[2 * CAP], q3 = p[3 * CAP];
                 a = make_float4(q0.x, q0.y, q1.x, q1.y);
                 b = make_float4(q2.x, q2.y, q3.x, q3.y);
+            } else if (MODE == 4) {  // soa16, 12 + 12 bytes used (the zero-pressure path of k_force: vx vy rho | x y yd)
+                const float* p = reinterpret_cast<const float*>(base + r * 16);
+                a = make_float4(p[0], p[1], p[2], 0.0f);
+                b = make_float4(p[4 * CAP], p[4 * CAP + 1], p[4 * CAP + 2], 0.0f);
+            } else if (MODE == 5) {  // 16-byte hot half (x y yd rho) + an 8-byte array (vx vy)
+                const float4* p = reinterpret_cast<const float4*>(base + r * 16);
+                const float2* q = reinterpret_cast<const float2*>(base + CAP * 16 + r * 8);
+                a = p[0];
+                const float2 v = q[0];
+                b = make_float4(v.x, v.y, 0.0f, 0.0f);
+            } else if (MODE == 6) {  // 16-byte hot half + the first 8 bytes of the other 16-byte half
+                const float4* p = reinterpret_cast<const float4*>(base + r * 16);
+                const float2* q = reinterpret_cast<const float2*>(base + CAP * 16 + r * 16);
+                a = p[0];
+                const float2 v = q[0];
+                b = make_float4(v.x, v.y, 0.0f, 0.0f);
             } else {  // private
                 const float4* p = reinterpret_cast<const float4*>(base + ((threadIdx.x & 63) << 4) + ((r & 1) << 11));
                 a = p[0];
@@ -72,10 +88,10 @@ int main() {
         CHECK(hipMemcpy(d_idx, h.data(), h.size() * 2, hipMemcpyHostToDevice));
         CHECK(hipMalloc(&d_out, 4096 * 256 * 4));
         typedef void (*K)(const uint16_t*, float*);
-        K kern[4] = {k<0>, k<1>, k<2>, k<3>};
-        const char* name[4] = {"aos32", "soa16", "soa8", "private"};
+        K kern[7] = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>};
+        const char* name[7] = {"aos32", "soa16", "soa8", "private", "soa16_12", "hot16+8", "hot16+8of16"};
         for (int blocks : {256, 1024}) {
-            for (int m = 0; m < 4; m++) {
+            for (int m = 0; m < 7; m++) {
                 hipEvent_t e0, e1;
                 CHECK(hipEventCreate(&e0));
                 CHECK(hipEventCreate(&e1));
