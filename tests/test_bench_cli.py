@@ -1,0 +1,57 @@
+"""bench.py's command line on a box without a GPU: the multi-GPU line must not depend on an external launcher any
+more (round 2: `python bench.py --gpus 8` raised SystemExit unless torch.distributed.run had started it), and every
+refusal is a clear message with a non-zero exit code -- never a hang, never a silent CPU fallback."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+needs_no_gpu = pytest.mark.skipif(torch.cuda.device_count() > 0, reason="checks the refusals of a GPU-less box")
+
+
+def _run(args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=300, env=e)
+
+
+@needs_no_gpu
+def test_single_gpu_bench_refuses_without_a_gpu():
+    r = _run(["--steps", "2", "--warmup", "1"])
+    assert r.returncode != 0 and "needs a GPU" in r.stderr and "no CPU fallback" in r.stderr
+
+
+@needs_no_gpu
+@pytest.mark.parametrize("extra", [[], ["--driver", "mg"]])
+def test_multi_gpu_bench_without_launcher_refuses_cleanly(extra):
+    """No WORLD_SIZE: bench.py would start its own ranks (or the one-process driver) -- here it must say that there is
+    no GPU, before spawning anything."""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"] + extra)
+    assert r.returncode != 0 and "needs a GPU" in r.stderr
+    assert "torch.distributed.run with --nproc-per-node" not in r.stderr  # (round 2's message)
+
+
+def test_launcher_mismatch_and_bad_arguments():
+    r = _run(["--gpus", "4"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in r.stderr
+    r = _run(["--gpus", "2", "--driver", "mg"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "ONE process" in r.stderr
+    assert _run(["--gpus", "0"]).returncode != 0
+    assert _run(["--workload", "nope"]).returncode != 0
+
+
+def test_workloads_are_baseline_configs():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.WORKLOADS["dam1m"] == ("dam", 1024, 1024)      # configs[1]
+    assert bench.WORKLOADS["box4m"] == ("box", 2048, 2048)      # configs[2]
+    assert bench.WORKLOADS["dam16m"] == ("dam", 4096, 4096)     # configs[3]
+    assert bench.WORKLOADS["dam8m"][1] ** 2 > 8_000_000         # configs[4]: 8M per GPU
+    s = bench.stats([5.0e9, 5.1e9, 4.9e9])
+    assert s["repeats"] == 3 and s["value_median"] == 5.0e9 and abs(s["spread"] - 0.04) < 1e-12
