@@ -57,7 +57,8 @@ extern "C" int sphhip_debug_read_stamps(unsigned long long* out, int tiles) {
 // slot -- is the canonical summation order, shared with oracle/sph_oracle.c (orc_stencil_ranges).
 //
 // All LDS of the pair kernels is one dynamic array (16-byte aligned base, no static __shared__ in
-// front of it): [PairRec rec[cap]] (force) or [float2 pos[cap]] (density) [int off[MAXC+1]] [int gs[MAXC]]
+// front of it): [32 * cap bytes of staged records: PairRec rec[cap] in the dense kernels; hot[cap] (16 B), vel[cap] (8 B),
+// prs[cap] (4 B) in k_force, see rec_load] (force) or [float2 pos[cap]] (density) [int off[MAXC+1]] [int gs[MAXC]]
 // [int wave_tmp[8]] [u8 queue[QCAP*256] | u32 masks[8*256]] (force only).
 // ---------------------------------------------------------------------------------------------
 constexpr int PAIR_MAXC = 3 * (PAIR_MAX_TILE_CELLS + 2);  // candidate cells of a tile (<= 256)
@@ -80,7 +81,8 @@ constexpr int PAIR_STAGE_BATCH = 4;  // candidates per thread whose global loads
 constexpr int PAIR_MASK_WORDS = FORCE_MAX_RANGE / 32;  // in-range bit masks handed from k_density to k_force
 static_assert(FORCE_SCAN_UNROLL - 1 <= PAIR_ROW_PAD, "scan unroll reads past the range end");
 
-// One staged neighbour candidate of k_force: 32 bytes, so that one shifted index addresses both halves.
+// One staged neighbour candidate of the dense force kernels: 32 bytes, so that one shifted index addresses both halves
+// (k_force itself keeps the same fields in three arrays: rec_load / rec_store below).
 struct __align__(16) PairRec {
     float4 aux;  // vx, vy, rho, P
     float2 pos;  // +inf for sentinels and invalid particles
