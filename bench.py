@@ -297,7 +297,7 @@ def workload_text(kind, n_total, rows, params):
 
 
 # ---- N > 1, one rank per GPU over torch.distributed (sph_amd/slab.py) -------------------------------------------------
-def run_slabs(name, scaling, steps, warmup, rebalance_every, local_rank, rank, world):
+def run_slabs(name, scaling, steps, warmup, rebalance_every, local_rank, rank, world, prime=0):
     """One slab-decomposed scene on the ranks of the default process group; returns the result dict on rank 0 (None
     elsewhere).  Timed region: barrier + device sync on both sides, MAX over ranks."""
     import numpy as np
@@ -335,9 +335,23 @@ def run_slabs(name, scaling, steps, warmup, rebalance_every, local_rank, rank, w
         # message or the particle capacity overflowed during the asynchronous steps; leaves the state as it is
         return int(slab.backend.column_histogram()[slab.c0:slab.c1].sum())
 
+    primer = None
+    if prime:
+        # set-up, as at N = 1 (run_single): a separate small scene on this rank's GPU, stepped right before the timed
+        # region so that the GPU enters it at its clocks; the slab's own state sees exactly `warmup` steps
+        from sph_amd.solver import Solver
+
+        p1, a1 = scenes.dam_break(1024, 1024)
+        primer = Solver(p1, n_max=len(a1), device=local_rank)
+        primer.upload(a1)
+        del a1
     slab.run(warmup, rebalance_every)
     torch.cuda.synchronize()
     counts_start = gather_ints(owned_now())
+    if primer is not None:
+        primer.stepSimulation(nsteps=prime)
+        primer.synchronize()
+        primer.close()
     # HIP events around the two force launches of a split step (boundary columns on the library's stream, interior
     # columns on its side stream), one step in eight
     inner.set_profiling_phases(["force", "force_interior"])
@@ -401,7 +415,7 @@ def run_slabs(name, scaling, steps, warmup, rebalance_every, local_rank, rank, w
             "halo_columns": HALO_COLS, "message_records_steady": [c for c in slab.caps[1:-1]],
             "bytes_sent_per_exchange_rank0": bytes_per_exchange,
         },
-        "workload_text": workload_text(kind, n_total, rows, params),
+        "workload_text": workload_text(kind, n_total, rows, params), "primed_steps": prime,
     }
     del slab
     return out
@@ -429,13 +443,13 @@ def main_ranks(args, world, rank, local_rank):
     name = args.workload or "dam16m"
     scaling = args.scaling or ("strong" if args.workload is None else "weak")
     reb = int(os.environ.get("SPH_BENCH_REBALANCE", str(args.rebalance_every)))
-    head = run_slabs(name, scaling, args.steps, args.warmup, reb, local_rank, rank, world)
+    head = run_slabs(name, scaling, args.steps, args.warmup, reb, local_rank, rank, world, prime=args.prime)
     extras = {}
     if not args.no_extra_scenes and args.workload is None:
         # configs[4]: 8M particles per GPU, weak scaling (fewer steps: a bounded addition to the run)
         st = max(args.steps // 2, 5)
         try:
-            r = run_slabs("dam8m", "weak", st, max(args.warmup // 2, 2), reb, local_rank, rank, world)
+            r = run_slabs("dam8m", "weak", st, max(args.warmup // 2, 2), reb, local_rank, rank, world, prime=args.prime)
             if rank == 0:
                 r["roofline"] = {k: r["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms")}
                 extras["dam8m_per_gpu_weak"] = r
@@ -456,7 +470,7 @@ def main_ranks(args, world, rank, local_rank):
             "roofline": head["roofline"], "roofline_valu": None,
             "phases_ms_per_step": head["phases_ms_per_step_rank0"],
             "pair_interactions_per_s": head["pair_interactions_per_s"], "mean_neighbors": head["mean_neighbors"],
-            "ups": args.steps / (head["ms_per_step"] * 1e-3 * args.steps),
+            "ups": args.steps / (head["ms_per_step"] * 1e-3 * args.steps), "primed_steps": head["primed_steps"],
         }
         if not args.no_extra_scenes and scaling == "strong":
             # the same scene on ONE GPU (rank 0's), for the strong-scaling ratio and the fp32-vector roofline of the kernel
@@ -661,8 +675,9 @@ def main():
     ap.add_argument("--driver", choices=["c10d", "mg"], default="c10d",
                     help="N > 1: c10d = one process per GPU over torch.distributed (sph_amd/slab.py); mg = one process, "
                     "libsph_mg.so (C++ driver, ncclCommInitAll)")
-    ap.add_argument("--prime", type=int, default=150, help="N = 1: steps run before the measured scene is (re-)uploaded, to bring the "
-                    "GPU to its clocks (set-up; the measured scene then does --warmup untimed and --steps timed steps)")
+    ap.add_argument("--prime", type=int, default=150, help="set-up steps that bring the GPU to its clocks before the measured scene "
+                    "does its --warmup untimed and --steps timed steps: at N = 1 on the scene itself, which is then uploaded "
+                    "again; at N > 1 (c10d driver) on a separate 1M scene on each rank's GPU, right before the timed region")
     ap.add_argument("--repeats", type=int, default=5, help="N = 1: timed intervals of --steps steps (value = the first; "
                     "median / min / max over all of them are reported beside it)")
     args = ap.parse_args()
