@@ -147,6 +147,55 @@ def stencil_candidates(solver, drv):
     return int((cnt * acc).sum())
 
 
+def zero_pressure_tiles(cell_start, cell_end, order, pressure_bits, nx, ny, tile_rows):
+    """Share of k_force's base tiles (one grid column x `tile_rows` rows with at least one particle) whose staged
+    candidates -- the 3x3 stencils of their cells -- all have pressure bits +0: those run the instantiation without the
+    pressure term (pairs.hip, force_terms<ZEROP>).  Host numpy over the cell table, off the timed path.  Tiles the device
+    cuts into sub-tiles stage smaller stencils, so the true share is at least this one.  -> (tiles, zero-pressure tiles)"""
+    import numpy as np
+
+    nz_sorted = (np.asarray(pressure_bits)[np.asarray(order)] != 0).astype(np.int64)
+    csum = np.concatenate([[0], np.cumsum(nz_sorted)])
+    cs, ce = np.asarray(cell_start, np.int64), np.asarray(cell_end, np.int64)
+    cell_nz = (csum[ce] - csum[cs]).reshape(nx, ny) > 0
+    cell_used = (ce - cs).reshape(nx, ny) > 0
+    near = np.zeros_like(cell_nz)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            sx0, sx1 = max(0, dx), nx + min(0, dx)
+            sy0, sy1 = max(0, dy), ny + min(0, dy)
+            near[sx0 - dx:sx1 - dx, sy0 - dy:sy1 - dy] |= cell_nz[sx0:sx1, sy0:sy1]
+    blocks = -(-ny // tile_rows)
+    pad = blocks * tile_rows - ny
+    used = np.pad(cell_used, ((0, 0), (0, pad))).reshape(nx, blocks, tile_rows).any(axis=2)
+    # (a tile stages the stencils of ALL its rows, empty cells included)
+    hot = np.pad(near, ((0, 0), (0, pad))).reshape(nx, blocks, tile_rows).any(axis=2)
+    return int(used.sum()), int((used & ~hot).sum())
+
+
+def pressure_paths(solver, params):
+    """Which force_terms instantiation the scene's tiles run: needs the densities / pressures of the current state
+    (call after computeDensityPressure)."""
+    import numpy as np
+
+    state = solver.download()
+    bits = np.ascontiguousarray(state["pressure"]).view(np.uint32)
+    nz = int(np.count_nonzero(bits))
+    out = {"particles_with_nonzero_pressure": nz, "max_density": float(state["density"].max()) if len(state) else 0.0,
+           "rest_density": float(params.rest_density)}
+    if nz == 0:
+        out["zero_pressure_tile_frac"] = 1.0
+        out["note"] = "every pressure is +0 (P = max(0, K (rho - rho0)), sph.cpp:52-53): every tile runs force_terms<ZEROP>"
+    else:
+        _, order, cs, ce = solver.cells()
+        rows = solver.tile_stats()["tile_rows"]
+        tiles, zero = zero_pressure_tiles(cs, ce, order, bits, solver.drv.nx, solver.drv.ny, max(rows, 1))
+        out["zero_pressure_tile_frac"] = zero / max(tiles, 1)
+        out["base_tiles"] = tiles
+        out["note"] = "base tiles (column x %d rows) whose 3x3 stencils hold no particle with P != +0; a lower bound where the device cuts tiles" % rows
+    return out
+
+
 def force_rooflines(n_launch, force_avg_s, pairs_local, cand_local, traffic=None, valu=None, kernel="k_force<fused integrate>"):
     """The two roofline blocks of the dominant kernel (fused force + integrate): HBM by algorithmic bytes, and FP32
     vector by SURVEY.md 8(d)'s algorithmic flop counts (the bound that actually applies at ~50 neighbours).
@@ -261,6 +310,7 @@ def run_single(name, steps, warmup, device, evolve=0, repeats=1, prime=0):
         pairs = solver.pair_count()
         counts = solver.neighbor_counts()
         cand = stencil_candidates(solver, solver.drv)
+        paths = pressure_paths(solver, params)
         force_avg_s = (f_ms / max(f_k, 1)) * 1e-3  # (f_k: the sampled launches)
         traffic, valu = committed_pmc(name if not evolve else "-")
         hbm, fp32 = force_rooflines(n, force_avg_s, pairs, cand, traffic, valu)
@@ -271,7 +321,7 @@ def run_single(name, steps, warmup, device, evolve=0, repeats=1, prime=0):
             "max_neighbors": int(counts.max()) - 1 if n else 0,
             "pair_interactions_per_s": 2.0 * pairs * steps / elapsed,
             "roofline": hbm, "roofline_valu": fp32, "phases_ms_per_step": breakdown, "tile_rounds": rounds,
-            "box": [float(params.xmax - params.xmin), float(params.ymax - params.ymin)],
+            "pressure_paths": paths, "box": [float(params.xmax - params.xmin), float(params.ymax - params.ymin)],
         }
         if repeats > 1:
             out.update(stats([n * steps / t for t in times]))
@@ -283,7 +333,7 @@ def run_single(name, steps, warmup, device, evolve=0, repeats=1, prime=0):
 def brief(d):
     """An extra scene's entry: the headline numbers without the long roofline notes."""
     o = {k: d[k] for k in ("workload", "particles", "grid", "steps", "warmup", "evolved_steps", "value", "unit", "ms_per_step",
-                           "mean_neighbors", "max_neighbors", "pair_interactions_per_s", "tile_rounds") if k in d}
+                           "mean_neighbors", "max_neighbors", "pair_interactions_per_s", "tile_rounds", "pressure_paths") if k in d}
     o["roofline"] = {k: d["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms")}
     if d.get("roofline_valu"):
         o["roofline_valu"] = {k: d["roofline_valu"][k] for k in ("achieved", "peak", "unit", "frac")}
@@ -609,6 +659,7 @@ def main_single(args):
         "phases_ms_per_step": head["phases_ms_per_step"],
         "pair_interactions_per_s": head["pair_interactions_per_s"], "mean_neighbors": head["mean_neighbors"],
         "ups": args.steps / (head["ms_per_step"] * 1e-3 * args.steps), "tile_rounds": head["tile_rounds"],
+        "pressure_paths": head["pressure_paths"],
     }
     for k in ("repeats", "value_median", "value_min", "value_max", "spread", "values", "primed_steps"):
         if k in head:

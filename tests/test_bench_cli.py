@@ -55,3 +55,29 @@ def test_workloads_are_baseline_configs():
     assert bench.WORKLOADS["dam8m"][1] ** 2 > 8_000_000         # configs[4]: 8M per GPU
     s = bench.stats([5.0e9, 5.1e9, 4.9e9])
     assert s["repeats"] == 3 and s["value_median"] == 5.0e9 and abs(s["spread"] - 0.04) < 1e-12
+
+
+def test_zero_pressure_tile_share_on_a_small_grid():
+    """bench.py's host recount of which base tiles stage only +0 pressures (the force_terms<ZEROP> path)."""
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    nx, ny = 4, 6  # column-major cell keys; one particle per cell, column 3 and cell (0, 5) empty
+    counts = np.ones((nx, ny), int)
+    counts[3, :] = 0
+    counts[0, 5] = 0
+    cs = np.concatenate([[0], np.cumsum(counts.reshape(-1))])[:-1]
+    ce = cs + counts.reshape(-1)
+    n = int(counts.sum())
+    order = np.random.RandomState(1).permutation(n)  # particle id per sorted slot
+    bits = np.zeros(n, np.uint32)
+    assert bench.zero_pressure_tiles(cs, ce, order, bits, nx, ny, 2) == (9, 9)
+    bits[order[cs[1 * ny + 2]]] = 0x3F800000  # the particle of cell (1, 2) has P = 1
+    # its pressure is staged by every tile that owns a cell of columns 0..2, rows 1..3
+    assert bench.zero_pressure_tiles(cs, ce, order, bits, nx, ny, 2) == (9, 3)  # the row blocks {4, 5} stay clear
+    assert bench.zero_pressure_tiles(cs, ce, order, bits, nx, ny, 3) == (6, 0)
+    bits[:] = 0
+    bits[order[cs[2 * ny + 5]]] = 0x80000000  # -0 is not +0: the kernel compares bits
+    assert bench.zero_pressure_tiles(cs, ce, order, bits, nx, ny, 3) == (6, 4)  # hot: rows 3..5 of columns 1 and 2

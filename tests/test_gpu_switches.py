@@ -91,6 +91,11 @@ def test_zero_pressure_shortcut_on_a_mixed_scene(monkeypatch, zero_p):
         n_p = int((d["pressure"] > 0).sum())
         assert 100 < n_p < len(a) // 4, n_p  # some pressure, mostly none
         assert orc.same_bits(d, O.density_cells(params, a.copy())[0])
+        # bench.py's report of the share of tiles on each path (host recount over the cell table)
+        import bench
+
+        paths = bench.pressure_paths(s, params)
+        assert paths["particles_with_nonzero_pressure"] == n_p and 0.0 < paths["zero_pressure_tile_frac"] < 1.0, paths
         for nsteps in (1, 6):
             s.upload(a)
             s.stepSimulation(nsteps=nsteps)
