@@ -273,26 +273,38 @@ struct TileQueue {
     int tile_cells;
 };
 
-// Workgroup b takes entry (b & 7) * gridDim/8 + (b >> 3), then strides by gridDim: chunk b & 7 of the
-// list goes to XCD b & 7.  The entry is read with wave-uniform (scalar) loads.  `tix` is threadIdx.x behind an
-// opaque barrier: without it the compiler hoists ~20 VGPRs of thread-index arithmetic out of the (rarely
-// repeated) loop and the force kernel drops from 4 to 3 workgroups per CU.
+// Chunk k = entries [k * ceil(total / 8), (k + 1) * ceil(total / 8)) of the list goes to XCD k: workgroup b (on XCD
+// b & 7; the grid is a multiple of 8) takes entry (b >> 3) of chunk b & 7, then strides by gridDim / 8 INSIDE its
+// chunk.  The chunks follow the list's true length, which only the device knows, not the grid the host chose from
+// a count that is 32 to 64 steps old (sph_throttle): while the chunks were cut by gridDim, every entry beyond a too
+// small grid fell to the first workgroups of chunk 0 -- when a settling dam break's tile count jumped from 4423 to
+// 4676 between two steps, XCD 0 got 838 entries instead of 585 and both pair kernels ran 40 % longer until the news
+// reached the host (tools/interval_probe.py: 0.228 instead of 0.193 ms per step over 50 steps), and a too large grid
+// starved XCD 7.  Now any grid is balanced: too small costs a second entry for some workgroups of every XCD alike,
+// too large costs workgroups that leave at once.
+// The entry is read with wave-uniform (scalar) loads.  `tix` is threadIdx.x behind an opaque barrier: without it the
+// compiler hoists ~20 VGPRs of thread-index arithmetic out of the (rarely repeated) loop and the force kernel drops
+// from 4 to 3 workgroups per CU.
 template <class Body>
 __device__ __forceinline__ void for_each_tile(const TileQueue& q, Body&& body) {
     const int total = *q.count;
-    int t = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int per_chunk = (total + 7) >> 3;
+    const int stride = max((int)(gridDim.x >> 3), 1);  // workgroups per chunk (pair_grid: a multiple of 8, >= 8)
+    const int first = (int)(blockIdx.x & 7) * per_chunk;
+    const int last = min(first + per_chunk, total);  // (< first for the chunks behind the end of a short list)
+    int t = first + (int)(blockIdx.x >> 3);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ((volatile int*)q.host_count)[0] = total;
         ((volatile int*)q.host_count)[1] = q.tile_cells;
         ((volatile int*)q.host_count)[2] = q.count[SPH_LONG_COUNT_OFFSET];
     }
-    while (t < total) {
+    while (t < last) {
         const TileDesc d = q.list[t];
         __syncthreads();  // the previous entry is done with the LDS image
         int tix = threadIdx.x;
         asm volatile("" : "+v"(tix));
         body(d, tix, t);
-        t += (int)gridDim.x;
+        t += stride;
     }
 }
 
@@ -1794,18 +1806,18 @@ static int ensure_tile_list(SphCtx* c, TileQueue& q) {
 }
 
 // Grid of a pair kernel: one workgroup per listed tile going by the last count that reached the host
-// (plus slack; the kernels stride, so an underestimate only costs balance), else one resident wave of
-// workgroups.  Always a multiple of 8 (one chunk per XCD).
+// (plus slack; the kernels stride inside their XCD's chunk, so any grid is correct and balanced: for_each_tile),
+// else one resident wave of workgroups.  Always a multiple of 8 (one chunk per XCD), at least 8, and never more
+// workgroups than the list has room for entries.
 static int pair_grid(SphCtx* c, const void* kern, int threads, size_t lds, int& grid) {
-    // Workgroup b reads list entry t(b) < grid before it knows the list length (for_each_tile): the grid must
-    // stay inside the list's allocation whatever the estimate says.
     const int grid_max = c->tile_list_cap & ~7;
     const int est = ((volatile int*)c->h_host_tiles)[0], est_cells = ((volatile int*)c->h_host_tiles)[1];
     if (est >= 0 && est_cells > 0) {
         // (a count taken under another tiling is rescaled; any grid size is correct)
         long long e = est_cells == c->tile_cells ? est : ((long long)est * est_cells + c->tile_cells - 1) / c->tile_cells;
-        e = (e + e / 128 + 8 + 7) & ~7ll;
+        e = (e + e / 64 + 8 + 7) & ~7ll;
         grid = (int)std::min<long long>(e, grid_max);
+        if (grid < 8) grid = 8;
         return SPHHIP_OK;
     }
     int per_cu = 0;
