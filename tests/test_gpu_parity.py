@@ -453,6 +453,27 @@ def test_full_size_dam_break_bit_exact():
     assert got["pos"][:, 1].min() >= params.ymin and got["pos"][:, 1].max() <= params.ymax
 
 
+def test_full_size_dam_break_through_the_settling_jump():
+    """BASELINE configs[1] at full size over 120 steps enqueued in ONE call: around step 76 the settling column crosses
+    a cell row and the pair kernels' work list grows by 6 % between two steps (4423 -> 4676 entries), while the host,
+    32 to 64 steps ahead (sph_throttle), still sizes the launches from the old length -- the entries beyond the grid
+    are reached by striding inside each XCD's chunk (pairs.hip: for_each_tile).  Whole state bit for bit against the
+    cell-list oracle (12 s of CPU), and the list did grow."""
+    params, a = scenes.dam_break(1024)
+    with Solver(params, n_max=len(a)) as s:
+        s.upload(a)
+        s.stepSimulation(nsteps=2)
+        s.synchronize()
+        before = s.tile_stats()["tiles"]
+        s.upload(a)
+        s.stepSimulation(nsteps=120)
+        got, ids = s.download(with_ids=True)
+        after = s.tile_stats()["tiles"]
+    assert after > before + before // 32, (before, after)
+    assert np.array_equal(np.sort(ids), np.arange(len(a)))
+    assert orc.same_bits(got, O.step_cells(params, a.copy(), 120))
+
+
 def test_full_size_uniform_box_bit_exact():
     """BASELINE configs[2] at full size (4M-particle box filled wall to wall, ~50 neighbours): neighbour
     counts and the whole state after 2 steps, bit for bit against the cell-list oracle."""
