@@ -382,8 +382,19 @@ def run_slabs(name, scaling, steps, warmup, rebalance_every, local_rank, rank, w
 
     def owned_now():
         # particles in this rank's own columns (ghost copies lie outside them); synchronises, and raises if a halo
-        # message or the particle capacity overflowed during the asynchronous steps; leaves the state as it is
-        return int(slab.backend.column_histogram()[slab.c0:slab.c1].sum())
+        # message or the particle capacity overflowed during the asynchronous steps; leaves the state as it is.
+        # Collective: a rank that raised alone would leave the others waiting in the next all-reduce.
+        failure, v = None, 0
+        try:
+            v = int(slab.backend.column_histogram()[slab.c0:slab.c1].sum())
+        except Exception as e:  # re-raised below, on every rank
+            failure = e
+        bad = allmax(1.0 if failure is not None else 0.0)
+        if failure is not None:
+            raise failure
+        if bad:
+            raise RuntimeError("another rank reported a failure (halo message or particle capacity overflow)")
+        return v
 
     primer = None
     if prime:

@@ -245,12 +245,27 @@ class SlabSolver:
         re-sizes the halo messages, per boundary: every rank sees the same numbers, so sender and receiver stay in
         agreement.  The first exchange after the move hands over whole columns and gets a message sized for exactly
         that (handover_caps); from then on the steady size applies.  Returns the new boundaries."""
-        self.backend.drop_ghosts()
-        h = torch.from_numpy(self.backend.column_histogram().astype(np.int64))
+        # A rank whose asynchronous steps overflowed a buffer learns of it here (the histogram download synchronises and
+        # raises).  It must still take part in the all-reduce, or its neighbours wait for it for ever: the failure
+        # travels as one more element of the reduced vector and every rank raises.
+        failure = None
+        try:
+            self.backend.drop_ghosts()
+            local = self.backend.column_histogram().astype(np.int64)
+        except Exception as e:  # noqa: BLE001 -- re-raised below, on every rank
+            failure = e
+            local = np.zeros(self.backend.drv.nx, np.int64)
+        h = torch.from_numpy(np.concatenate([local, [1 if failure is not None else 0]]))
         dev = getattr(self.backend, "device", torch.device("cpu"))
         h = h.to(dev)
         dist.all_reduce(h, group=self.group)
-        hist = h.cpu().numpy()
+        h = h.cpu().numpy()
+        if h[-1]:
+            if failure is not None:
+                raise failure
+            raise RuntimeError("slab rebalance: %d other rank(s) reported a failure (halo message or particle capacity "
+                               "overflow); this rank's state is intact but the decomposition is not" % int(h[-1]))
+        hist = h[:-1]
         self.last_hist = hist
         before = self.owned_counts()
         old = list(self.bounds)
@@ -396,6 +411,22 @@ class SlabSolver:
         """Host synchronisation point: raises if any asynchronous step overflowed a buffer."""
         chk = getattr(self.backend, "check", None)
         return chk() if chk else self.backend.n
+
+    def check_all(self):
+        """check() as a collective: every rank calls it, and if any rank's check fails every rank raises (a rank that
+        raised alone would leave the others waiting in their next collective).  Returns this rank's particle count."""
+        failure, n = None, 0
+        try:
+            n = self.check()
+        except Exception as e:  # noqa: BLE001 -- re-raised below
+            failure = e
+        flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int64, device=getattr(self.backend, "device", torch.device("cpu")))
+        dist.all_reduce(flag, group=self.group)
+        if failure is not None:
+            raise failure
+        if int(flag.item()):
+            raise RuntimeError("slab check: %d other rank(s) reported a failure (halo message or particle capacity overflow)" % int(flag.item()))
+        return n
 
 
 def records_from_particles(a, ids):

@@ -106,6 +106,53 @@ def test_large_boundary_shift_fits_the_handover_message(tmp_path):
     assert b[3] > 15  # (from 9: boundaries move one neighbour's width at a time, the last one first)
 
 
+def _failing_worker(rank, world, port, out_dir):
+    """Rank 1's backend reports an overflow at its next synchronising call (as the library does: sticky device flag,
+    raised by the histogram download / sync_counts); rank 0 is healthy."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import datetime
+
+    from fake_backend import FakeSlabBackend
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        params, a = _scene("dam")
+        backend = FakeSlabBackend(params)
+        hist = np.bincount(grid_column(a["pos"][:, 0], params, backend.drv), minlength=backend.drv.nx)
+        slab = SlabSolver(backend, params, balanced_bounds(hist, world), hist=hist)
+        distribute(slab, a)
+        slab.step(2)
+        if rank == 1:
+            def boom():
+                raise RuntimeError("halo message overflow (simulated)")
+
+            backend.column_histogram = boom
+            backend.check = boom
+        seen = []
+        for call in (slab.rebalance, slab.check_all):
+            try:
+                call()
+                seen.append("ok")
+            except RuntimeError as e:
+                seen.append(str(e))
+        with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+            f.write("\n".join(seen))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_fails_every_rank_instead_of_hanging_them(tmp_path):
+    """A rank that finds an overflow at a rebalance (or at check_all) must not leave its neighbours waiting in the
+    all-reduce it never joins: the failure travels with the reduced vector and every rank raises."""
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = open(tmp_path / "rank0.txt").read().splitlines()
+    r1 = open(tmp_path / "rank1.txt").read().splitlines()
+    assert all("other rank(s) reported a failure" in m for m in r0), r0
+    assert all("simulated" in m for m in r1), r1
+
+
 def test_message_sizes_from_the_histogram():
     hist = np.zeros(60, np.int64)
     hist[:40] = 100
