@@ -472,6 +472,11 @@ int sph_rank_big_setup() {
 // The arrival order is not deterministic; the (key, id) order after k_rank_reorder is.
 // R pos 8, W key 4 + rank 4; scan 2 x 8 B per cell; scatter R 12, W 12 per particle.
 // ---------------------------------------------------------------------------------------------
+#ifndef COUNT_ROUNDS
+#define COUNT_ROUNDS 4
+#endif
+// COUNT_ROUNDS particles per thread, a workgroup-width apart, stage by stage (position loads, then the run heads'
+// atomics, then the stores), so that the loads and the returning atomics of the rounds are in flight together.
 __global__ __launch_bounds__(256) void k_cell_count(DevConsts c, const float2* __restrict__ pos,
                                                      const int* __restrict__ d_n, uint32_t* __restrict__ keys,
                                                      uint32_t* __restrict__ rank, int* __restrict__ cell_cnt,
@@ -480,46 +485,70 @@ __global__ __launch_bounds__(256) void k_cell_count(DevConsts c, const float2* _
                                                      int drop_hi_cell, int col_min, int col_max,
                                                      int* __restrict__ err) {
     const int n = *d_n;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = i < n;
+    const int i0 = blockIdx.x * (256 * COUNT_ROUNDS) + threadIdx.x;
     // Lazy ghost drop (slab steps): the first *n_sorted slots are still in the order of the previous sort,
     // whose table says which slot range the owned columns were; everything else among them is a stale
     // ghost copy.  Such a particle gets the key 0xffffffff, is not counted and not scattered.
-    bool dead = false;
-    if (prev_table && ok && i < *n_sorted) dead = i < prev_table[drop_lo_cell] || i >= prev_table[drop_hi_cell];
-    uint32_t key = 0xffffffffu;
-    if (ok && !dead) {
-        float2 p = pos[i];
-        int cx = sph_cell_coord(p.x, c.xmin, c.inv_cell, c.nx);
-        int cy = sph_cell_coord(p.y, c.ymin, c.inv_cell, c.ny);
-        if (cx < col_min || cx >= col_max) {  // outside the columns the cell table covers (a slab and its reach)
-            dead = true;
-            atomicOr(err, SPH_ERR_OUT_OF_SLAB);
-        } else {
-            key = (uint32_t)(cx * c.ny + cy);
-        }
+    int keep_lo = 0, keep_hi = 0, sorted = 0;
+    if (prev_table) {
+        sorted = *n_sorted;
+        keep_lo = prev_table[drop_lo_cell];
+        keep_hi = prev_table[drop_hi_cell];
     }
     const int lane = sph_lane_id();
-    const uint32_t prev = __shfl_up(key, 1, 64);
-    const bool head = ok && (lane == 0 || prev != key);  // (runs of dead particles are runs too, but count nothing)
-    const unsigned long long heads = __ballot(head);
-    const int n_ok = __popcll(__ballot(ok));  // the in-range lanes are a prefix of the wave
     const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);  // lanes 0..lane
-    const unsigned long long below = heads & upto;
-    const int start = below ? 63 - __clzll((long long)below) : 0;  // head lane of this lane's run
-    int base = 0;
-    if (head && !dead) {
-        const unsigned long long above = heads & ~upto;
-        const int next = above ? __ffsll((long long)above) - 1 : n_ok;
-        base = atomicAdd(&cell_cnt[key], next - lane);
+    float2 p[COUNT_ROUNDS];
+    bool live[COUNT_ROUNDS];  // in range and not a stale ghost
+#pragma unroll
+    for (int r = 0; r < COUNT_ROUNDS; r++) {
+        const int i = i0 + r * 256;
+        live[r] = i < n && !(i < sorted && (i < keep_lo || i >= keep_hi));
+        p[r] = live[r] ? pos[i] : make_float2(0.0f, 0.0f);
     }
-    base = __shfl(base, start, 64);
-    if (ok) {
-        keys[i] = key;
-        rank[i] = (uint32_t)(base + lane - start);
+    uint32_t key[COUNT_ROUNDS];
+    int base[COUNT_ROUNDS], start[COUNT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < COUNT_ROUNDS; r++) {
+        const bool ok = i0 + r * 256 < n;
+        bool dead = !live[r];
+        key[r] = 0xffffffffu;
+        if (live[r]) {
+            int cx = sph_cell_coord(p[r].x, c.xmin, c.inv_cell, c.nx);
+            int cy = sph_cell_coord(p[r].y, c.ymin, c.inv_cell, c.ny);
+            if (cx < col_min || cx >= col_max) {  // outside the columns the cell table covers (a slab and its reach)
+                dead = true;
+                atomicOr(err, SPH_ERR_OUT_OF_SLAB);
+            } else {
+                key[r] = (uint32_t)(cx * c.ny + cy);
+            }
+        }
+        const uint32_t prev = __shfl_up(key[r], 1, 64);
+        const bool head = ok && (lane == 0 || prev != key[r]);  // (runs of dead particles are runs too, but count nothing)
+        const unsigned long long heads = __ballot(head);
+        const int n_ok = __popcll(__ballot(ok));  // the in-range lanes are a prefix of the wave
+        const unsigned long long below = heads & upto;
+        start[r] = below ? 63 - __clzll((long long)below) : 0;  // head lane of this lane's run
+        base[r] = 0;
+        if (head && !dead) {
+            const unsigned long long above = heads & ~upto;
+            const int next = above ? __ffsll((long long)above) - 1 : n_ok;
+            base[r] = atomicAdd(&cell_cnt[key[r]], next - lane);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < COUNT_ROUNDS; r++) {
+        const int i = i0 + r * 256;
+        const int b = __shfl(base[r], start[r], 64);
+        if (i < n) {
+            keys[i] = key[r];
+            rank[i] = (uint32_t)(b + lane - start[r]);
+        }
     }
 }
 
+#ifndef SCATTER_ROUNDS
+#define SCATTER_ROUNDS 4
+#endif
 __global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t* __restrict__ keys,
                                                        const uint32_t* __restrict__ rank,
                                                        const uint32_t* __restrict__ idv, const int* __restrict__ d_n,
@@ -533,15 +562,32 @@ __global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t* __restrict
         sph_tile_list_thread((int)(blockIdx.x * blockDim.x + threadIdx.x), cell_start, nx, ny, tl, err);
         return;
     }
+    // SCATTER_ROUNDS particles per thread, a workgroup-width apart (every access stays coalesced), all loads of a stage
+    // issued before the first use: with one particle per thread the kernel ran at the latency of its chain
+    // key -> cell_start[key] -> store (2.5 TB/s at 16M particles with every wave slot of the GPU filled), not at the
+    // bandwidth of HBM.
     const int n = *d_n;
-    const int i = ((int)blockIdx.x - head_blocks) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = keys[i];
-    if (k == 0xffffffffu) return;  // dropped (k_cell_count)
-    const int slot = cell_start[k] + (int)rank[i];
-    skeys[slot] = k;
-    perm[slot] = (uint32_t)i;
-    ids_sorted[slot] = idv[i] & SPH_ID_MASK;
+    const int base = ((int)blockIdx.x - head_blocks) * (256 * SCATTER_ROUNDS) + (int)threadIdx.x;
+    uint32_t k[SCATTER_ROUNDS], rk[SCATTER_ROUNDS], id[SCATTER_ROUNDS];
+    int cs[SCATTER_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SCATTER_ROUNDS; r++) {
+        const int i = base + r * 256;
+        const bool ok = i < n;
+        k[r] = ok ? keys[i] : 0xffffffffu;  // 0xffffffff: dropped by k_cell_count, or behind the end
+        rk[r] = ok ? rank[i] : 0u;
+        id[r] = ok ? idv[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < SCATTER_ROUNDS; r++) cs[r] = k[r] != 0xffffffffu ? cell_start[k[r]] : 0;
+#pragma unroll
+    for (int r = 0; r < SCATTER_ROUNDS; r++) {
+        if (k[r] == 0xffffffffu) continue;
+        const int slot = cs[r] + (int)rk[r];
+        skeys[slot] = k[r];
+        perm[slot] = (uint32_t)(base + r * 256);
+        ids_sorted[slot] = id[r] & SPH_ID_MASK;
+    }
 }
 
 // Exclusive prefix sum over len ints in place, chunks of SCAN_CHUNK: chunk sums, then every chunk adds
@@ -819,7 +865,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
                                    r_len, zero_buf + len, r_parts, c->d_err);
                 LAUNCH_CHECK();
             } else if (n > 0) {
-                hipLaunchKernelGGL(k_cell_count, dim3((n + 255) / 256), dim3(256), 0, st, c->dc, c->pos, c->d_n, c->keys2,
+                hipLaunchKernelGGL(k_cell_count, dim3((n + 256 * COUNT_ROUNDS - 1) / (256 * COUNT_ROUNDS)), dim3(256), 0, st, c->dc, c->pos, c->d_n, c->keys2,
                                    c->perm2, c->cell_start, prev_table, c->counters + SPH_N_SORTED_SLOT,
                                    c->slice_lo * c->dc.ny, c->slice_hi * c->dc.ny, clo, chi, c->d_err);
                 LAUNCH_CHECK();
@@ -853,7 +899,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
                 sph_tile_list_args(c, tl, lo, hi);
                 head = (tl.nthreads + 255) / 256;
             }
-            hipLaunchKernelGGL(k_cell_scatter, dim3((n + 255) / 256 + head), dim3(256), 0, st, c->keys2, c->perm2, c->idv, c->d_n,
+            hipLaunchKernelGGL(k_cell_scatter, dim3((n + 256 * SCATTER_ROUNDS - 1) / (256 * SCATTER_ROUNDS) + head), dim3(256), 0, st, c->keys2, c->perm2, c->idv, c->d_n,
                                c->cell_start, c->keys, c->perm, c->ids_sorted, head, c->dc.nx, c->dc.ny, tl, c->d_err);
             LAUNCH_CHECK();
         }
