@@ -305,6 +305,9 @@ __global__ __launch_bounds__(256) void k_sufmin_apply(int* __restrict__ a, int l
 // of the slab partition and of the arrival order of migrated particles.
 // R: key 4, cell_start 8, ids ~cell size * 4 (cached), perm 4, state 16|24 + idv 4;  W: 16|24 + 4.
 // ---------------------------------------------------------------------------------------------
+#ifndef REORDER_ROUNDS
+#define REORDER_ROUNDS 2
+#endif
 template <bool CARRY_DENSITY>
 __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict__ skeys,
                                                        const uint32_t* __restrict__ perm,
@@ -328,49 +331,75 @@ __global__ __launch_bounds__(256) void k_rank_reorder(const uint32_t* __restrict
         return;
     }
     const int n = *d_n;  // particle count lives on the device (asynchronous slab steps)
-    // The ids of the workgroup's 256 slots go to LDS: cell-mates sit in consecutive slots, so nearly every id the
+    // The ids of the workgroup's slots go to LDS: cell-mates sit in consecutive slots, so nearly every id the
     // ranking loop below compares with is one of them.  (Read from global memory, one load instruction per cell-mate
     // with the lanes of a wave in four or five different cells, the loop kept the texture path busy for half of the
     // kernel's time: 16 M particles 0.287 ms, 2.6 TB/s.)
-    __shared__ uint32_t s_id[256];
-    const int base = ((int)blockIdx.x - head_blocks) * (int)blockDim.x;
-    const int s = base + (int)threadIdx.x;
-    const bool live = s < n;
-    const uint32_t my = live ? ids_sorted[s] : 0xffffffffu;
-    s_id[threadIdx.x] = my;
-    uint32_t k = 0xffffffffu, src = 0, id_in = 0;
-    float2 p_in = make_float2(0.0f, 0.0f), v_in = p_in;
-    float d_in = 0.0f, pr_in = 0.0f;
-    if (live) {
-        k = skeys[s];
-        // (the state is gathered first: its loads depend on perm only and travel while the chain key -> cell table -> ids runs)
-        src = perm[s];
-        p_in = pos[src];
-        v_in = vel[src];
-        id_in = idv[src];
-        if (CARRY_DENSITY) {
-            d_in = rho[src];
-            pr_in = prs[src];
+    // REORDER_ROUNDS slots per thread, a workgroup-width apart: the gathers of all rounds are issued before the first
+    // use (the kernel is a chain of dependent loads -- perm -> state, key -> cell table -> ids -- and ran at their
+    // latency with one slot per thread).
+    constexpr int TILE = 256 * REORDER_ROUNDS;
+    __shared__ uint32_t s_id[TILE];
+    const int base = ((int)blockIdx.x - head_blocks) * TILE;
+    bool live[REORDER_ROUNDS];
+    uint32_t my[REORDER_ROUNDS], k[REORDER_ROUNDS], id_in[REORDER_ROUNDS];
+    float2 p_in[REORDER_ROUNDS], v_in[REORDER_ROUNDS];
+    float d_in[REORDER_ROUNDS], pr_in[REORDER_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < REORDER_ROUNDS; r++) {
+        const int s = base + r * 256 + (int)threadIdx.x;
+        live[r] = s < n;
+        my[r] = live[r] ? ids_sorted[s] : 0xffffffffu;
+        s_id[r * 256 + threadIdx.x] = my[r];
+    }
+#pragma unroll
+    for (int r = 0; r < REORDER_ROUNDS; r++) {
+        const int s = base + r * 256 + (int)threadIdx.x;
+        k[r] = 0xffffffffu;
+        id_in[r] = 0;
+        p_in[r] = v_in[r] = make_float2(0.0f, 0.0f);
+        d_in[r] = pr_in[r] = 0.0f;
+        if (live[r]) {
+            k[r] = skeys[s];
+            // (the state is gathered first: its loads depend on perm only and travel while the chain key -> cell table -> ids runs)
+            const uint32_t src = perm[s];
+            p_in[r] = pos[src];
+            v_in[r] = vel[src];
+            id_in[r] = idv[src];
+            if (CARRY_DENSITY) {
+                d_in[r] = rho[src];
+                pr_in[r] = prs[src];
+            }
         }
     }
     __syncthreads();
-    if (!live || k >= (uint32_t)ncell) return;  // (never for a slot below the count; a stale key must not become an address)
-    const int a = cell_start[k], b = cell_start[k + 1];
-    // a crowded cell is ranked by k_rank_big (sorted ids instead of this loop over all cell-mates)
-    if (skip_big && b - a > RANK_BIG_MIN) return;
-    int rank = 0;
-    int t = a;
-    for (const int e = min(b, base); t < e; t++) rank += (ids_sorted[t] < my) ? 1 : 0;        // cell-mates before this workgroup's slots
-    for (const int e = min(b, base + 256); t < e; t++) rank += (s_id[t - base] < my) ? 1 : 0;  // ... among them
-    for (; t < b; t++) rank += (ids_sorted[t] < my) ? 1 : 0;                                  // ... behind them
-    const int dst = a + rank;
-    pos_o[dst] = p_in;
-    vel_o[dst] = v_in;
-    if (CARRY_DENSITY) {
-        rho_o[dst] = d_in;
-        prs_o[dst] = pr_in;
+    int a[REORDER_ROUNDS], b[REORDER_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < REORDER_ROUNDS; r++) {
+        const bool ok = live[r] && k[r] < (uint32_t)ncell;  // (never false for a slot below the count; a stale key must not become an address)
+        a[r] = ok ? cell_start[k[r]] : 0;
+        b[r] = ok ? cell_start[k[r] + 1] : 0;
+        live[r] = ok;
     }
-    idv_o[dst] = id_in;
+#pragma unroll
+    for (int r = 0; r < REORDER_ROUNDS; r++) {
+        if (!live[r]) continue;
+        // a crowded cell is ranked by k_rank_big (sorted ids instead of this loop over all cell-mates)
+        if (skip_big && b[r] - a[r] > RANK_BIG_MIN) continue;
+        int rank = 0;
+        int t = a[r];
+        for (const int e = min(b[r], base); t < e; t++) rank += (ids_sorted[t] < my[r]) ? 1 : 0;         // cell-mates before this workgroup's slots
+        for (const int e = min(b[r], base + TILE); t < e; t++) rank += (s_id[t - base] < my[r]) ? 1 : 0;  // ... among them
+        for (; t < b[r]; t++) rank += (ids_sorted[t] < my[r]) ? 1 : 0;                                  // ... behind them
+        const int dst = a[r] + rank;
+        pos_o[dst] = p_in[r];
+        vel_o[dst] = v_in[r];
+        if (CARRY_DENSITY) {
+            rho_o[dst] = d_in[r];
+            prs_o[dst] = pr_in[r];
+        }
+        idv_o[dst] = id_in[r];
+    }
 }
 
 // The same ranking for crowded cells.  The loop above reads every cell-mate's id per particle: quadratic in the cell
@@ -959,7 +988,7 @@ int sph_grid_build(SphCtx* c, bool carry_density) {
     c->tiles_valid = false;
     if (n > 0) {
         PhaseScope ps(c, SPHHIP_PH_REORDER);
-        const int nb = (n + 255) / 256;
+        const int nb = (n + 256 * REORDER_ROUNDS - 1) / (256 * REORDER_ROUNDS);
         // head workgroups (counting path only): zeroing of the idle cell table
         int head = 0, lo = 0, hi = 0;
         if (c->grid_counting) {
